@@ -1,0 +1,98 @@
+/*
+ * tsqr_mi.h -- C ABI of the MI355X-native tall-skinny QR engine (libtsqr_mi.so).
+ *
+ * This is the drop-in boundary for the reference's hot path
+ *     mtk::qr::qr<compute_mode, Reorthogonalize>() / mtk::qr::buffer
+ * (reference src/blockqr.hpp:59-175, src/blockqr.cu:394-433).  The C++ templates in
+ * include/tsqr/blockqr.hpp forward to these entry points; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions (same as the reference): all matrices column-major; q, r, a and every work
+ * buffer are DEVICE pointers owned by the caller (h_wl is pinned host memory); the call is
+ * blocking -- it returns after the stream is idle (reference src/blockqr.cu:140); nothing
+ * is allocated inside; `a` may be overwritten (it is for n > 64).
+ */
+#ifndef TSQR_MI_H
+#define TSQR_MI_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mtk::qr::compute_mode, same names and order as reference src/blockqr.hpp:12-23 */
+enum tsqr_mi_compute_mode {
+	TSQR_MI_FP16_NOTC = 0,
+	TSQR_MI_FP16_TC_NOCOR = 1,
+	TSQR_MI_FP32_NOTC = 2,         /* supported: exact fp32 (VALU + v_mfma_f32_16x16x4_f32) */
+	TSQR_MI_FP32_TC_COR = 3,       /* supported: bf16 MFMA with 3-way split error correction */
+	TSQR_MI_FP32_TC_NOCOR = 4,
+	TSQR_MI_MIXED_TC_COR_EMU = 5,
+	TSQR_MI_TF32_TC_COR = 6,       /* no xf32 MFMA on gfx950: unsupported */
+	TSQR_MI_TF32_TC_COR_EMU = 7,
+	TSQR_MI_TF32_TC_NOCOR = 8,
+	TSQR_MI_TF32_TC_NOCOR_EMU = 9
+};
+
+/* mtk::qr::state_t codes, reference src/blockqr.hpp:27-29, plus one new code */
+#define TSQR_MI_SUCCESS               0   /* success_factorization */
+#define TSQR_MI_ERROR_INVALID_SIZE    1   /* error_invalid_matrix_size: n > m, m == 0 or n == 0 */
+#define TSQR_MI_ERROR_UNSUPPORTED     2   /* new: compute_mode without a gfx950 implementation */
+/* negative return values: -(hipError_t) of the failing runtime call */
+
+int tsqr_mi_version(void);
+const char* tsqr_mi_last_error(void);
+
+/* replaces mtk::qr::get_working_{q,r,l}_size (reference src/blockqr.hpp:55-57, src/blockqr.cu:34-42).
+ * Element counts (float / float / unsigned).  Never smaller than the reference's own formulas. */
+size_t tsqr_mi_working_q_size(size_t m, size_t n);
+size_t tsqr_mi_working_r_size(size_t m, size_t n);
+size_t tsqr_mi_working_l_size(size_t m);
+/* the reorthogonalisation scratch of mtk::qr::buffer::allocate (reference src/blockqr.hpp:91): 2*256 + 16 m floats */
+size_t tsqr_mi_working_reorth_size(size_t m);
+/* mtk::tsqr::get_batch_size_log2 / get_batch_size (reference src/tsqr.cu:39-44) */
+size_t tsqr_mi_batch_size_log2(size_t m);
+size_t tsqr_mi_batch_size(size_t m);
+
+/*
+ * replaces mtk::qr::qr<mode, Reorthogonalize>(q, ldq, r, ldr, a, lda, m, n, wq, wr, reorth_r, d_wl, h_wl, handle)
+ * (reference src/blockqr.hpp:142-154).  `stream` is a hipStream_t (takes the place of the stream the
+ * reference pulls out of its cublasHandle_t, src/blockqr.cu:58-59).  R: the full n x n upper triangle is
+ * written and the strict lower triangle is set to exact zeros.
+ */
+int tsqr_mi_qr_f32(int mode, int reorth,
+                   float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                   size_t m, size_t n,
+                   void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
+                   void* stream);
+
+/*
+ * Staged entry points used by the row-partitioned multi-GPU path: every rank
+ * factors its row block, the n x n R factors are all-gathered (RCCL), every rank folds the stack,
+ * and forms its rows of Q.  n <= 64.
+ */
+/* R (n x n, ldr) of the local block a (m x n); m may be < n (stack of R factors is fine too). */
+int tsqr_mi_local_r_f32(float* r, size_t ldr, const float* a, size_t lda, size_t m, size_t n,
+                        void* wq, void* wr, void* stream);
+/* q (m x n) = a (m x n) * inverse(r); q may alias a. */
+int tsqr_mi_apply_rinv_f32(int mode, float* q, size_t ldq, const float* a, size_t lda,
+                           const float* r, size_t ldr, size_t m, size_t n,
+                           void* wq, void* stream);
+/* r (n x n) <- r2 * r (upper triangular product, used after a reorthogonalisation sweep) */
+int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t n, void* wq, void* stream);
+
+/* Row-partitioned TSQR over an RCCL communicator (ncclComm_t passed as void*).  Every rank passes its
+ * own row block; r is identical on all ranks on return.  n <= 64. */
+int tsqr_mi_qr_f32_dist(int mode, int reorth,
+                        float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                        size_t m_local, size_t n,
+                        void* wq, void* wr, float* gather_buf /* nranks*n*n floats */,
+                        void* nccl_comm, int nranks, void* stream);
+
+/* tuning knobs (0 = keep default): waves targeted by the first fold level, chunks folded per wave on tree levels */
+void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSQR_MI_H */

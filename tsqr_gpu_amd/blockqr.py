@@ -1,0 +1,172 @@
+"""Python mirror of the reference's host interface for the tall-skinny QR path.
+
+Same names and argument meaning as reference src/blockqr.hpp:
+  compute_mode (:12-23), tsqr_colmun_size (:25), state_t codes (:27-29),
+  get_working_{q,r,l}_size (:55-57), buffer (:59-140), qr (:142-175).
+
+Everything here is plumbing over the C ABI of csrc/libtsqr_mi.so (include/tsqr_mi.h): the
+arithmetic lives in hand-written HIP kernels.  There is NO CPU fallback: importing works without
+the library (so sizes/enums can be inspected), but any call that needs it raises RuntimeError.
+torch is used only to own device memory and streams.
+"""
+import ctypes
+import enum
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtsqr_mi.so")
+
+
+class compute_mode(enum.IntEnum):
+    """mtk::qr::compute_mode, reference src/blockqr.hpp:12-23 (same order)."""
+    fp16_notc = 0
+    fp16_tc_nocor = 1
+    fp32_notc = 2
+    fp32_tc_cor = 3
+    fp32_tc_nocor = 4
+    mixed_tc_cor_emu = 5
+    tf32_tc_cor = 6
+    tf32_tc_cor_emu = 7
+    tf32_tc_nocor = 8
+    tf32_tc_nocor_emu = 9
+
+
+tsqr_colmun_size = 16                 # reference src/blockqr.hpp:25 (name kept, typo included)
+success_factorization = 0             # reference src/blockqr.hpp:28
+error_invalid_matrix_size = 1         # reference src/blockqr.hpp:29
+error_unsupported_mode = 2            # new: modes without a gfx950 implementation
+
+C_ABI_SYMBOLS = [
+    "tsqr_mi_version", "tsqr_mi_last_error",
+    "tsqr_mi_working_q_size", "tsqr_mi_working_r_size", "tsqr_mi_working_l_size",
+    "tsqr_mi_working_reorth_size", "tsqr_mi_batch_size_log2", "tsqr_mi_batch_size",
+    "tsqr_mi_qr_f32", "tsqr_mi_local_r_f32", "tsqr_mi_apply_rinv_f32", "tsqr_mi_rmul_f32",
+    "tsqr_mi_qr_f32_dist", "tsqr_mi_set_tuning",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libtsqr_mi.so; raise loudly if it was not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "tsqr_gpu_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tsqr_gpu_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    sz, vp, ci = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
+    L.tsqr_mi_version.restype = ci
+    L.tsqr_mi_last_error.restype = ctypes.c_char_p
+    for name, args in [("tsqr_mi_working_q_size", [sz, sz]), ("tsqr_mi_working_r_size", [sz, sz]),
+                       ("tsqr_mi_working_l_size", [sz]), ("tsqr_mi_working_reorth_size", [sz]),
+                       ("tsqr_mi_batch_size_log2", [sz]), ("tsqr_mi_batch_size", [sz])]:
+        getattr(L, name).restype = sz
+        getattr(L, name).argtypes = args
+    L.tsqr_mi_qr_f32.restype = ci
+    L.tsqr_mi_qr_f32.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp]
+    L.tsqr_mi_local_r_f32.restype = ci
+    L.tsqr_mi_local_r_f32.argtypes = [vp, sz, vp, sz, sz, sz, vp, vp, vp]
+    L.tsqr_mi_apply_rinv_f32.restype = ci
+    L.tsqr_mi_apply_rinv_f32.argtypes = [ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp]
+    L.tsqr_mi_rmul_f32.restype = ci
+    L.tsqr_mi_rmul_f32.argtypes = [vp, sz, vp, sz, sz, vp, vp]
+    L.tsqr_mi_qr_f32_dist.restype = ci
+    L.tsqr_mi_qr_f32_dist.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, ci, vp]
+    L.tsqr_mi_set_tuning.restype = None
+    L.tsqr_mi_set_tuning.argtypes = [ci, ci]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().tsqr_mi_last_error().decode()
+
+
+# ---- mtk::qr::get_working_*_size (reference src/blockqr.hpp:55-57) ----------------------------------
+def get_working_q_size(m, n):
+    return lib().tsqr_mi_working_q_size(m, n)
+
+
+def get_working_r_size(m, n):
+    return lib().tsqr_mi_working_r_size(m, n)
+
+
+def get_working_l_size(m):
+    return lib().tsqr_mi_working_l_size(m)
+
+
+def get_batch_size_log2(m):
+    """mtk::tsqr::get_batch_size_log2, reference src/tsqr.cu:39-41."""
+    return lib().tsqr_mi_batch_size_log2(m)
+
+
+def get_batch_size(m):
+    return lib().tsqr_mi_batch_size(m)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class buffer:
+    """mtk::qr::buffer<mode, Reorthogonalize>, reference src/blockqr.hpp:59-140.
+
+    Fields dwq, dwr, dw_reorth_r, dl (device) and hl (pinned host) as in the reference;
+    allocate() twice raises RuntimeError like the reference's std::runtime_error (:77-79).
+    """
+
+    def __init__(self, mode=compute_mode.fp32_tc_cor, reorthogonalize=False, device="cuda"):
+        self.mode = compute_mode(mode)
+        self.reorthogonalize = bool(reorthogonalize)
+        self.device = device
+        self.dwq = self.dwr = self.dw_reorth_r = self.dl = self.hl = None
+        self.total_memory_size = 0
+
+    def allocate(self, m, n):
+        import torch
+        if self.dwq is not None or self.dwr is not None or self.dl is not None or self.hl is not None:
+            raise RuntimeError("The buffer has been already allocated")
+        wq, wr, wl = get_working_q_size(m, n), get_working_r_size(m, n), get_working_l_size(m)
+        self.dwq = torch.empty(max(wq, 1), dtype=torch.float32, device=self.device)
+        self.dwr = torch.empty(max(wr, 1), dtype=torch.float32, device=self.device)
+        self.dl = torch.empty(max(wl, 1), dtype=torch.int32, device=self.device)
+        self.hl = torch.empty(max(wl, 1), dtype=torch.int32).pin_memory()
+        self.total_memory_size = 4 * (wq + wr + wl)
+        if self.reorthogonalize:
+            ro = lib().tsqr_mi_working_reorth_size(m)
+            self.dw_reorth_r = torch.empty(max(ro, 1), dtype=torch.float32, device=self.device)
+            self.total_memory_size += 4 * ro
+
+    def destroy(self):
+        self.dwq = self.dwr = self.dw_reorth_r = self.dl = self.hl = None
+
+    def get_device_memory_size(self):
+        return self.total_memory_size
+
+
+def qr(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
+    """mtk::qr::qr<mode, Reorthogonalize>(q, ldq, r, ldr, a, lda, m, n, buffer, handle).
+
+    q, r, a: float32 torch tensors on the GPU holding column-major data (any shape; only data_ptr is
+    used).  `stream` (torch.cuda.Stream or None = current) takes the place of the cublasHandle_t, whose
+    only role in the reference is to carry the stream (src/blockqr.cu:58-59).  Blocking, returns state_t.
+    Runtime failures raise RuntimeError (the reference throws std::runtime_error from CUTF_CHECK_ERROR).
+    """
+    import torch
+    mode = bf.mode if mode is None else compute_mode(mode)
+    reorth = bf.reorthogonalize if reorthogonalize is None else bool(reorthogonalize)
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    st = lib().tsqr_mi_qr_f32(int(mode), int(reorth), _ptr(q), ldq, _ptr(r), ldr, _ptr(a), lda, m, n,
+                              _ptr(bf.dwq), _ptr(bf.dwr), _ptr(bf.dw_reorth_r), _ptr(bf.dl), _ptr(bf.hl),
+                              stream.cuda_stream)
+    if st < 0:
+        raise RuntimeError("tsqr_mi_qr_f32 failed: %s" % last_error())
+    return st
+
+
+def set_tuning(level0_waves=0, tree_chunks_per_wave=0):
+    lib().tsqr_mi_set_tuning(level0_waves, tree_chunks_per_wave)

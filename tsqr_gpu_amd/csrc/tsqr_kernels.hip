@@ -1,0 +1,477 @@
+// tsqr_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the tall-skinny QR engine.
+//
+// Replaces, with a different (MI355X-first) algorithm, the device side of the reference hot path:
+//   qr32x16_batched_kernel / qr32x16_core      reference src/tcqr32x16.cu:1373-1581   -> fold_kernel
+//   tsqr_backward / tsqr_backward_layer0       reference src/tsqr.cu:143-204, 591-656  -> apply_kernel
+//   cuBLAS GEMMs between panels                reference src/blockqr.cu:92-116         -> proj_* / update_kernel
+//
+// Data layout used by every streaming kernel ("(c,q) layout"): a wave owns a chunk of 64 rows x NP
+// columns (NP = 16*NT).  Lane l = 16*q + c holds, for every 16-column tile ct, column 16*ct+c and the
+// sixteen rows {16*rt + 4*q + i : rt,i in 0..3} in registers p[ct][4*rt+i].  This is exactly the
+// C/D layout of the 16x16 MFMAs (col = lane&15, row = 4*(lane>>4)+reg), loads/stores are 16 B per lane
+// along the column-major leading dimension, a column reduction is 16 in-lane FMAs + one 4-lane (q) sum,
+// and "broadcast the pivot column to every column of the tile" is one DPP row_newbcast.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+
+namespace tsqrmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global access
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+	if constexpr (I < N) {
+		f(std::integral_constant<int, I>{});
+		static_for<I + 1, N>(f);
+	}
+}
+
+// value of lane (16*q + K) for every lane of DPP row q  (v_mov_b32_dpp row_newbcast:K)
+template <int K>
+__device__ __forceinline__ float bcast16(float x) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + K, 0xf, 0xf, true));
+}
+
+// sum over the four lanes {c, c+16, c+32, c+48}; result in all four  (v_permlane32_swap + v_permlane16_swap)
+__device__ __forceinline__ float xq_sum(float x) {
+	const unsigned u = __builtin_bit_cast(unsigned, x);
+	const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+	const float y = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+	const unsigned v = __builtin_bit_cast(unsigned, y);
+	const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+	return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// chunk load / store in the (c,q) layout
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void load_chunk(float (&p)[NT][16], const float* __restrict__ src, size_t ld,
+                                           size_t row0, size_t m, int n, int c, int q) {
+	const bool full = (row0 + 64 <= m);
+#pragma unroll
+	for (int ct = 0; ct < NT; ct++) {
+		const int col = 16 * ct + c;
+		const float* base = src + (size_t)col * ld + row0 + 4 * q;
+		if (col < n) {
+			if (full) {
+#pragma unroll
+				for (int rt = 0; rt < 4; rt++) {
+					const f32x4u v = *reinterpret_cast<const f32x4u*>(base + 16 * rt);
+					p[ct][4 * rt + 0] = v[0]; p[ct][4 * rt + 1] = v[1]; p[ct][4 * rt + 2] = v[2]; p[ct][4 * rt + 3] = v[3];
+				}
+			} else {
+#pragma unroll
+				for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+					for (int i = 0; i < 4; i++) {
+						const size_t row = row0 + 16 * rt + 4 * q + i;
+						p[ct][4 * rt + i] = (row < m) ? base[16 * rt + i] : 0.0f;
+					}
+			}
+		} else {
+#pragma unroll
+			for (int r = 0; r < 16; r++) p[ct][r] = 0.0f;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// fold_kernel: streaming TPQRT.  Every wave folds `cpw` consecutive 64-row chunks of src into one
+// upper-triangular R (NP x NP, kept packed in LDS):   R <- R-factor of [R ; chunk]
+// using unblocked Householder reflectors whose top part is e_k (so R stays triangular and only
+// row k of R changes in step k).  All arithmetic fp32 FMA (used by both compute modes).
+// ---------------------------------------------------------------------------------------------
+struct FoldArgs {
+	const float* src; size_t ld; size_t m; int n;     // source matrix (m x n, column-major)
+	int nchunks; int cpw; int nwaves;                 // chunk = 64 rows; wave w folds chunks [w*cpw, (w+1)*cpw)
+	float* dst; size_t dst_ld; int rows_store; int cols_store;   // wave w writes rows [w*rows_store, ...) of dst
+};
+
+template <int NT, int K>
+__device__ __forceinline__ void hh_step(float (&p)[NT][16], float* __restrict__ Rw, int c, int q, int n) {
+	constexpr int S = K >> 4, KK = K & 15, NP = 16 * NT;
+	constexpr int OFF = K * NP - (K * (K - 1)) / 2;      // packed row K: entry (K, col) at OFF + col - K
+	if (K >= n) return;                                  // wave-uniform
+	float x[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++) x[r] = bcast16<KK>(p[S][r]);
+	float d[NT];
+#pragma unroll
+	for (int ct = S; ct < NT; ct++) {
+		float acc = 0.0f;
+#pragma unroll
+		for (int r = 0; r < 16; r++) acc = fmaf(x[r], p[ct][r], acc);
+		d[ct] = xq_sum(acc);
+	}
+	const float ss = bcast16<KK>(d[S]);                  // ||x||^2 of the pivot column (chunk part)
+	const float rkk = Rw[OFF];
+	const float nrm = sqrtf(fmaf(rkk, rkk, ss));
+	const bool nz = nrm > 0.0f;
+	const float beta = (rkk >= 0.0f) ? -nrm : nrm;       // -sign(rkk)*||.||, sign(0) = +1
+	const float inv = nz ? 1.0f / (rkk - beta) : 0.0f;   // v = x * inv (top entry of v is 1)
+	const float rb = nz ? 1.0f / beta : 0.0f;
+	const float tau = nz ? (beta - rkk) * rb : 0.0f;
+#pragma unroll
+	for (int ct = S; ct < NT; ct++) {
+		const int col = 16 * ct + c;
+		const float rkc = Rw[OFF + col - K];             // lanes with col < K read a harmless neighbour
+		const float w = fmaf(inv, d[ct], rkc);           // w = r_kc + v^T b_c
+		const bool act = col > K;
+		const float g = act ? w * rb : 0.0f;             // b_c -= tau*w*v  ==  b_c += x * (w/beta)
+		if (q == 0) {
+			if (act) Rw[OFF + col - K] = fmaf(-tau, w, rkc);
+			else if (col == K) Rw[OFF] = nz ? beta : rkk;
+		}
+#pragma unroll
+		for (int r = 0; r < 16; r++) p[ct][r] = fmaf(x[r], g, p[ct][r]);
+	}
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void fold_kernel(const FoldArgs a) {
+	constexpr int NP = 16 * NT;
+	constexpr int RP = (NP * (NP + 1)) / 2 + 16;         // packed upper triangle (+ slack for masked reads)
+	__shared__ float Rs[4][RP];
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int gw = blockIdx.x * 4 + wv;
+	if (gw >= a.nwaves) return;                          // whole waves leave; no barrier in this kernel
+	const int c = lane & 15, q = lane >> 4;
+	float* Rw = Rs[wv];
+	for (int i = lane; i < RP; i += 64) Rw[i] = 0.0f;
+
+	float p[NT][16];
+	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
+	for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+		load_chunk<NT>(p, a.src, a.ld, (size_t)ch * 64, a.m, a.n, c, q);
+		static_for<0, NP>([&](auto kc) { hh_step<NT, decltype(kc)::value>(p, Rw, c, q, a.n); });
+	}
+	// write R: lane <-> row, loop over columns (consecutive lanes -> consecutive addresses)
+	float* dst = a.dst + (size_t)gw * a.rows_store;
+	if (lane < a.rows_store) {
+		const int off = lane * NP - (lane * (lane - 1)) / 2;
+		for (int col = 0; col < a.cols_store; col++) {
+			const float v = (lane <= col && lane < NP && col < NP) ? Rw[off + col - lane] : 0.0f;
+			dst[(size_t)col * a.dst_ld + lane] = v;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// trinv_kernel: Z = inverse of the n x n upper-triangular R (fp64 arithmetic, fp32 in/out), written
+// zero-padded to NP x NP column-major (ld NP).  One wave; lane j solves R z = e_j by back substitution.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void trinv_kernel(float* __restrict__ z, const float* __restrict__ r, size_t ldr,
+                                                   int n, int NP) {
+	__shared__ float Rl[64 * 65];
+	const int j = threadIdx.x;
+	for (int col = 0; col < n; col++)
+		Rl[col * 65 + j] = (j < n) ? r[(size_t)col * ldr + j] : 0.0f;   // Rl[col][row]
+	__syncthreads();
+	double zc[64];
+#pragma unroll
+	for (int i = 0; i < 64; i++) zc[i] = 0.0;
+	if (j < n) {
+#pragma unroll
+		for (int i = 63; i >= 0; i--) {
+			if (i <= j && i < n) {                      // runtime mask, static register index
+				double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+				for (int k = i + 1; k < 64; k++)
+					if (k <= j) s -= (double)Rl[k * 65 + i] * zc[k];
+				zc[i] = s / (double)Rl[i * 65 + i];
+			}
+		}
+	}
+	if (j < NP) {
+#pragma unroll
+		for (int i = 0; i < 64; i++)
+			if (i < NP) z[(size_t)j * NP + i] = (float)zc[i];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply_kernel: Q[rows, 0:n] = A[rows, 0:n] * Z   (Z = NP x NP upper triangular, zero padded).
+// ENGINE 0 (fp32_notc):   v_mfma_f32_16x16x4_f32, exact fp32 FMA chains.
+// ENGINE 1 (fp32_tc_cor): v_mfma_f32_16x16x32_bf16 on a 3-way bf16 split (hi, mid, lo) of both operands;
+//   six products per tile, accumulated smallest terms first:  (mid*mid + hi*lo + lo*hi) + (hi*mid + mid*hi) + hi*hi
+//   -- the error-correction idea of the reference's fp32_tc_cor (src/tcqr32x16.cu:669-819) carried to ~24 bits.
+// ---------------------------------------------------------------------------------------------
+struct ApplyArgs {
+	const float* a; size_t lda; float* q; size_t ldq; size_t m; int n;
+	const float* z;                     // NP x NP, ld NP
+	int nchunks; int cpw; int nwaves;
+};
+
+__device__ __forceinline__ unsigned f2bf(float x) {    // round-to-nearest-even bf16 bits (finite inputs)
+	const unsigned u = __builtin_bit_cast(unsigned, x);
+	return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+	h = f2bf(x);
+	const float r1 = x - __builtin_bit_cast(float, h << 16);
+	m = f2bf(r1);
+	const float r2 = r1 - __builtin_bit_cast(float, m << 16);
+	l = f2bf(r2);
+}
+
+template <int ENGINE, int NT>
+__global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
+	constexpr int NP = 16 * NT;
+	constexpr int AS = 68;                               // column stride (floats) of the per-wave A tile
+	constexpr int ZS = NP + 16;                          // row stride of the fp32 Z image
+	constexpr int KT = (NP + 31) / 32;                   // K-steps of 32 for the bf16 engine
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	float* At_all = reinterpret_cast<float*>(smem);                       // [4][NP*AS]
+	char* zbase = smem + sizeof(float) * 4 * NP * AS;
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int gw = blockIdx.x * 4 + wv;
+	const int c = lane & 15, q = lane >> 4;
+
+	// ---- stage Z into LDS in operand form (all 256 threads) ----
+	if constexpr (ENGINE == 0) {
+		float* Zs = reinterpret_cast<float*>(zbase);     // Zs[k][j], stride ZS
+		for (int idx = threadIdx.x; idx < NP * NP; idx += 256) {
+			const int k = idx % NP, j = idx / NP;
+			Zs[k * ZS + j] = a.z[(size_t)j * NP + k];
+		}
+	} else {
+		// Zb[part][kt][ct][lane][8] : B operand of mfma 16x16x32: lane (j=l&15, qq=l>>4) holds Z[32kt+8qq+jj][16ct+j]
+		unsigned short* Zb = reinterpret_cast<unsigned short*>(zbase);
+		for (int idx = threadIdx.x; idx < KT * NT * 64 * 8; idx += 256) {
+			const int jj = idx & 7, l = (idx >> 3) & 63, ct = (idx >> 9) % NT, kt = (idx >> 9) / NT;
+			const int k = 32 * kt + 8 * (l >> 4) + jj, j = 16 * ct + (l & 15);
+			const float v = (k < NP) ? a.z[(size_t)j * NP + k] : 0.0f;
+			unsigned h, m, lo;
+			split3(v, h, m, lo);
+			const int o = ((kt * NT + ct) * 64 + l) * 8 + jj;
+			Zb[0 * KT * NT * 512 + o] = (unsigned short)h;
+			Zb[1 * KT * NT * 512 + o] = (unsigned short)m;
+			Zb[2 * KT * NT * 512 + o] = (unsigned short)lo;
+		}
+	}
+	__syncthreads();
+	if (gw >= a.nwaves) return;
+
+	float* At = At_all + wv * NP * AS;
+	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
+	for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+		const size_t row0 = (size_t)ch * 64;
+		{
+			float p[NT][16];
+			load_chunk<NT>(p, a.a, a.lda, row0, a.m, a.n, c, q);
+#pragma unroll
+			for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+				for (int rt = 0; rt < 4; rt++) {
+					f32x4 v = {p[ct][4 * rt], p[ct][4 * rt + 1], p[ct][4 * rt + 2], p[ct][4 * rt + 3]};
+					*reinterpret_cast<f32x4*>(&At[(16 * ct + c) * AS + 16 * rt + 4 * q]) = v;
+				}
+		}
+		__builtin_amdgcn_wave_barrier();
+		const bool full = (row0 + 64 <= a.m);
+#pragma unroll 1
+		for (int rt = 0; rt < 4; rt++) {
+			f32x4 acc[NT];
+#pragma unroll
+			for (int ct = 0; ct < NT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+			const int arow = 16 * rt + c;                 // A operand: lane&15 <-> row inside the 16-row tile
+			if constexpr (ENGINE == 0) {
+				const float* Zs = reinterpret_cast<const float*>(zbase);
+#pragma unroll
+				for (int t = 0; t < NP / 4; t++) {
+					const int k = 4 * t + q;
+					const float av = At[k * AS + arow];
+#pragma unroll
+					for (int ct = 0; ct < NT; ct++) {
+						if (4 * t <= 16 * ct + 15) {          // Z[k][j] = 0 for k > j
+							const float bv = Zs[k * ZS + 16 * ct + c];
+							acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ct], 0, 0, 0);
+						}
+					}
+				}
+			} else {
+				const unsigned short* Zb = reinterpret_cast<const unsigned short*>(zbase);
+				bf16x8 ah[KT], am[KT], al[KT];
+#pragma unroll
+				for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+					for (int jj = 0; jj < 8; jj++) {
+						const int k = 32 * kt + 8 * q + jj;
+						const float v = (k < NP) ? At[k * AS + arow] : 0.0f;
+						unsigned h, m, lo;
+						split3(v, h, m, lo);
+						ah[kt][jj] = (short)h; am[kt][jj] = (short)m; al[kt][jj] = (short)lo;
+					}
+				}
+				constexpr int PS = KT * NT * 512;             // shorts per part
+#pragma unroll
+				for (int ct = 0; ct < NT; ct++) {
+					bf16x8 bh[KT], bm[KT], bl[KT];
+#pragma unroll
+					for (int kt = 0; kt < KT; kt++) {
+						if (32 * kt <= 16 * ct + 15) {
+							const int o = ((kt * NT + ct) * 64 + lane) * 8;
+							bh[kt] = *reinterpret_cast<const bf16x8*>(&Zb[0 * PS + o]);
+							bm[kt] = *reinterpret_cast<const bf16x8*>(&Zb[1 * PS + o]);
+							bl[kt] = *reinterpret_cast<const bf16x8*>(&Zb[2 * PS + o]);
+						}
+					}
+					f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+					for (int kt = 0; kt < KT; kt++)
+						if (32 * kt <= 16 * ct + 15) {
+							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[kt], bm[kt], s, 0, 0, 0);
+							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kt], bl[kt], s, 0, 0, 0);
+							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kt], bh[kt], s, 0, 0, 0);
+						}
+#pragma unroll
+					for (int kt = 0; kt < KT; kt++)
+						if (32 * kt <= 16 * ct + 15) {
+							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kt], bm[kt], s, 0, 0, 0);
+							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[kt], bh[kt], s, 0, 0, 0);
+						}
+#pragma unroll
+					for (int kt = 0; kt < KT; kt++)
+						if (32 * kt <= 16 * ct + 15)
+							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kt], bh[kt], s, 0, 0, 0);
+					acc[ct] = s;
+				}
+			}
+			// D layout: col = lane&15, rows 4*(lane>>4) + i of this 16-row tile
+#pragma unroll
+			for (int ct = 0; ct < NT; ct++) {
+				const int col = 16 * ct + c;
+				if (col < a.n) {
+					float* dst = a.q + (size_t)col * a.ldq + row0 + 16 * rt + 4 * q;
+					if (full) {
+						*reinterpret_cast<f32x4u*>(dst) = acc[ct];
+					} else {
+#pragma unroll
+						for (int i = 0; i < 4; i++)
+							if (row0 + 16 * rt + 4 * q + i < a.m) dst[i] = acc[ct][i];
+					}
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// panel coupling for n > 64 (block modified Gram-Schmidt between 64-column panels), fp32 FMA.
+//   proj_partial_kernel : S_part[slab] = Qb[slab rows]^T * Ap[slab rows]      (pb x pc, pb,pc <= 64)
+//   proj_reduce_kernel  : S = sum over slabs (fixed order -> deterministic); also written into R
+//   update_kernel       : Ap -= Qb * S
+// replaces the two cuBLAS GEMMs of reference src/blockqr.cu:92-116.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void proj_partial_kernel(float* __restrict__ part, const float* __restrict__ qb, size_t ldq,
+                                                           const float* __restrict__ ap, size_t lda, size_t m,
+                                                           int pb, int pc, size_t rows_per_slab) {
+	__shared__ float Qs[64][65];
+	__shared__ float As[64][65];
+	const int tid = threadIdx.x;
+	const int ti = tid & 15, tj = tid >> 4;              // thread owns S[4*ti..+3][4*tj..+3]
+	float acc[4][4];
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+#pragma unroll
+		for (int j = 0; j < 4; j++) acc[i][j] = 0.0f;
+	const size_t r_begin = (size_t)blockIdx.x * rows_per_slab;
+	const size_t r_end = min(m, r_begin + rows_per_slab);
+	for (size_t r0 = r_begin; r0 < r_end; r0 += 64) {
+		for (int idx = tid; idx < 64 * 64; idx += 256) {
+			const int rr = idx & 63, cc = idx >> 6;
+			const size_t row = r0 + rr;
+			const bool ok = row < r_end;
+			Qs[cc][rr] = (ok && cc < pb) ? qb[(size_t)cc * ldq + row] : 0.0f;
+			As[cc][rr] = (ok && cc < pc) ? ap[(size_t)cc * lda + row] : 0.0f;
+		}
+		__syncthreads();
+#pragma unroll 4
+		for (int rr = 0; rr < 64; rr++) {
+			float qv[4], av[4];
+#pragma unroll
+			for (int i = 0; i < 4; i++) { qv[i] = Qs[4 * ti + i][rr]; av[i] = As[4 * tj + i][rr]; }
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+#pragma unroll
+				for (int j = 0; j < 4; j++) acc[i][j] = fmaf(qv[i], av[j], acc[i][j]);
+		}
+		__syncthreads();
+	}
+	float* out = part + (size_t)blockIdx.x * 4096;
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+#pragma unroll
+		for (int j = 0; j < 4; j++) out[(4 * tj + j) * 64 + 4 * ti + i] = acc[i][j];   // [col j][row i]
+}
+
+__global__ __launch_bounds__(256) void proj_reduce_kernel(float* __restrict__ s, float* __restrict__ r, size_t ldr,
+                                                          const float* __restrict__ part, int nslab, int pb, int pc) {
+	for (int idx = threadIdx.x + blockIdx.x * 256; idx < 4096; idx += 256 * gridDim.x) {
+		float acc = 0.0f;
+		for (int t = 0; t < nslab; t++) acc += part[(size_t)t * 4096 + idx];
+		s[idx] = acc;
+		const int i = idx & 63, j = idx >> 6;
+		if (i < pb && j < pc) r[(size_t)j * ldr + i] = acc;
+	}
+}
+
+__global__ __launch_bounds__(256) void update_kernel(float* __restrict__ ap, size_t lda, const float* __restrict__ qb, size_t ldq,
+                                                     const float* __restrict__ s, size_t m, int pb, int pc) {
+	__shared__ float Ss[64 * 64];                        // Ss[j*64 + i] = S[i][j]
+	for (int idx = threadIdx.x; idx < 4096; idx += 256) Ss[idx] = s[idx];
+	__syncthreads();
+	const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (row >= m) return;
+	float acc[64];
+#pragma unroll
+	for (int j = 0; j < 64; j++) acc[j] = 0.0f;
+	for (int i = 0; i < pb; i++) {
+		const float qv = qb[(size_t)i * ldq + row];
+#pragma unroll
+		for (int j = 0; j < 64; j++) acc[j] = fmaf(qv, Ss[j * 64 + i], acc[j]);
+	}
+#pragma unroll
+	for (int j = 0; j < 64; j++)
+		if (j < pc) ap[(size_t)j * lda + row] -= acc[j];
+}
+
+// R <- R2 * R1 (n x n upper triangular, fp64 accumulation).  r1 is a packed copy (ld n) of the old R.
+__global__ __launch_bounds__(256) void rmul_kernel(float* __restrict__ r, size_t ldr, const float* __restrict__ r2, size_t ldr2,
+                                                   const float* __restrict__ r1, size_t ldr1, int n) {
+	const size_t total = (size_t)n * n;
+	for (size_t idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)256 * gridDim.x) {
+		const int i = (int)(idx % n), j = (int)(idx / n);
+		double acc = 0.0;
+		if (i <= j)
+			for (int k = i; k <= j; k++) acc += (double)r2[(size_t)k * ldr2 + i] * (double)r1[(size_t)j * ldr1 + k];
+		r[(size_t)j * ldr + i] = (float)acc;
+	}
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(float* __restrict__ dst, size_t ldd, const float* __restrict__ src, size_t lds,
+                                                     int rows, int cols) {
+	const size_t total = (size_t)rows * cols;
+	for (size_t idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)256 * gridDim.x) {
+		const int i = (int)(idx % rows), j = (int)(idx / rows);
+		dst[(size_t)j * ldd + i] = src[(size_t)j * lds + i];
+	}
+}
+
+__global__ __launch_bounds__(256) void zero_lower_kernel(float* __restrict__ r, size_t ldr, int n) {
+	const size_t total = (size_t)n * n;
+	for (size_t idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)256 * gridDim.x) {
+		const int i = (int)(idx % n), j = (int)(idx / n);
+		if (i > j) r[(size_t)j * ldr + i] = 0.0f;
+	}
+}
+
+}  // namespace tsqrmi

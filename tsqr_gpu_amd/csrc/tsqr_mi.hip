@@ -1,0 +1,361 @@
+// tsqr_mi.hip -- host orchestration and the extern "C" ABI of libtsqr_mi.so (declared in include/tsqr_mi.h).
+//
+// Host-side counterpart of the reference's block_qr_core / block_qr_reorthogonalization_core
+// (reference src/blockqr.cu:45-178, 180-390) and tsqr16_geq32 (reference src/tsqr.cu:1064-1279),
+// re-designed for MI355X:
+//   * panel width 64 instead of 16: for n <= 64 there is no inter-panel coupling at all;
+//   * R by a streaming Householder TSQR (fold_kernel) followed by a short fold tree over the per-wave
+//     R factors -- the R-stack reduction of the reference, with fan-in 4 instead of 2;
+//   * Q = A * inverse(R) on the MFMA units (apply_kernel): "indirect TSQR".  Its loss of
+//     orthogonality grows like cond(A)*eps, slower than the reference's 16-wide block Gram-Schmidt
+//     without reorthogonalisation; Reorthogonalize=true runs a second sweep on Q (R <- R2*R), which
+//     restores ||Q^T Q - I|| to O(eps) as the reference's BCGS2 does.
+//   * no host synchronisation inside; one hipStreamSynchronize at the end (the reference call is blocking).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <string>
+
+#include "../../include/tsqr_mi.h"
+#include "tsqr_kernels.hip"
+
+namespace {
+
+thread_local std::string g_last_error;
+int g_level0_waves = 2048;
+int g_tree_cpw = 4;
+
+constexpr size_t PW = 64;          // panel width
+constexpr int NSLAB = 512;         // row slabs of the projection kernel
+
+inline int fail(hipError_t e, const char* what) {
+	g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+	return -(int)e;
+}
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_, #expr); } while (0)
+
+inline size_t cdiv(size_t a, size_t b) { return (a + b - 1) / b; }
+inline size_t np_of(size_t n) { return 16 * cdiv(std::min(n, PW), 16); }
+
+// ---- reference-compatible size rules (reference src/tsqr.cu:39-60, src/blockqr.cu:34-42) ----
+size_t ref_bs_log2(size_t m) {
+	const unsigned c = (unsigned)std::ceil(std::log2((float)m));
+	return (size_t)(std::max(5u, c) - 5u);
+}
+size_t ref_bs(size_t m) { return (size_t)1 << ref_bs_log2(m); }
+size_t ref_wq(size_t m, size_t n) { n = std::min<size_t>(16, n); return n * m + 2 * n * n * (ref_bs(m) - 1); }
+size_t ref_wr(size_t m, size_t n) { n = std::min<size_t>(16, n); const size_t b = ref_bs(m); return n * n * b + n * n * b / 2; }
+
+// ---- fold plan: level 0 over the matrix, then levels over the stacks of per-wave R factors ----
+struct Plan {
+	size_t NP;
+	int nlevels;
+	size_t rows[24];     // source rows of each level
+	int nch[24], cpw[24], nw[24];
+	size_t stack_a;      // floats needed in wr (levels 0, 2, 4, ... write here)
+	size_t stack_b;      // floats needed in wq (levels 1, 3, ... write here)
+};
+
+Plan make_plan(size_t m, size_t n) {
+	Plan p{};
+	p.NP = np_of(n);
+	size_t rows = m;
+	int lv = 0;
+	for (;;) {
+		const size_t nch = cdiv(rows, 64);
+		size_t cpw = (lv == 0) ? std::max<size_t>(1, cdiv(nch, (size_t)g_level0_waves)) : (size_t)g_tree_cpw;
+		size_t nw = cdiv(nch, cpw);
+		if (nw <= 1) { nw = 1; cpw = nch; }
+		// a level must shrink the row count, otherwise fold everything in one wave
+		if (nw > 1 && nw * p.NP >= rows) { nw = 1; cpw = nch; }
+		p.rows[lv] = rows; p.nch[lv] = (int)nch; p.cpw[lv] = (int)cpw; p.nw[lv] = (int)nw;
+		if (nw > 1) {
+			const size_t sz = nw * p.NP * p.NP;
+			if (lv % 2 == 0) p.stack_a = std::max(p.stack_a, sz); else p.stack_b = std::max(p.stack_b, sz);
+		}
+		lv++;
+		if (nw == 1) break;
+		rows = nw * p.NP;
+	}
+	p.nlevels = lv;
+	return p;
+}
+
+// layout of wq (floats): [stack_b][Z: 4096][S: 4096][part: NSLAB*4096][R1 copy: n*n][R2: n*n]
+struct WqLayout { size_t z, s, part, r1, r2, total; };
+WqLayout wq_layout(size_t m, size_t n) {
+	const Plan p = make_plan(m, n);
+	WqLayout L{};
+	size_t o = p.stack_b;
+	o = (o + 63) & ~(size_t)63;
+	L.z = o; o += 4096;
+	L.s = o; o += 4096;
+	L.part = o; o += (n > PW ? (size_t)NSLAB * 4096 : 0);
+	L.r1 = o; o += n * n;
+	L.r2 = o; o += n * n;
+	L.total = o;
+	return L;
+}
+
+template <int NT> int launch_fold(const tsqrmi::FoldArgs& a, hipStream_t st) {
+	const int blocks = (a.nwaves + 3) / 4;
+	hipLaunchKernelGGL(tsqrmi::fold_kernel<NT>, dim3(blocks), dim3(256), 0, st, a);
+	return 0;
+}
+int dispatch_fold(int NT, const tsqrmi::FoldArgs& a, hipStream_t st) {
+	switch (NT) {
+		case 1: return launch_fold<1>(a, st);
+		case 2: return launch_fold<2>(a, st);
+		case 3: return launch_fold<3>(a, st);
+		default: return launch_fold<4>(a, st);
+	}
+}
+
+// R (n x n, ldr; full block written, zeros below the diagonal) of src (m x n), n <= 64
+int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n,
+           float* wq, float* wr, hipStream_t st) {
+	const Plan p = make_plan(m, n);
+	const int NT = (int)(p.NP / 16);
+	const float* cur = src; size_t cur_ld = ld;
+	for (int lv = 0; lv < p.nlevels; lv++) {
+		tsqrmi::FoldArgs a{};
+		a.src = cur; a.ld = cur_ld; a.m = p.rows[lv];
+		a.n = (lv == 0) ? (int)n : (int)p.NP;            // stacks are NP wide (padding columns are zero)
+		if (lv > 0) a.n = (int)n;                        // ... but only the first n columns carry data
+		a.nchunks = p.nch[lv]; a.cpw = p.cpw[lv]; a.nwaves = p.nw[lv];
+		if (p.nw[lv] == 1) {
+			a.dst = r; a.dst_ld = ldr; a.rows_store = (int)n; a.cols_store = (int)n;
+		} else {
+			float* stack = (lv % 2 == 0) ? wr : wq;
+			a.dst = stack; a.dst_ld = (size_t)p.nw[lv] * p.NP; a.rows_store = (int)p.NP; a.cols_store = (int)p.NP;
+			cur = stack; cur_ld = a.dst_ld;
+		}
+		dispatch_fold(NT, a, st);
+		HIPCHK(hipGetLastError());
+	}
+	return 0;
+}
+
+template <int E, int NT> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
+	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
+	const size_t lds = sizeof(float) * 4 * NP * 68 + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)3 * KT * NT * 512 * 2);
+	static bool attr_done = false;
+	if (!attr_done) {
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_kernel<E, NT>),
+		                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		attr_done = true;
+	}
+	const int blocks = (a.nwaves + 3) / 4;
+	hipLaunchKernelGGL((tsqrmi::apply_kernel<E, NT>), dim3(blocks), dim3(256), lds, st, a);
+	return 0;
+}
+template <int E> int dispatch_apply_nt(int NT, const tsqrmi::ApplyArgs& a, hipStream_t st) {
+	switch (NT) {
+		case 1: return launch_apply<E, 1>(a, st);
+		case 2: return launch_apply<E, 2>(a, st);
+		case 3: return launch_apply<E, 3>(a, st);
+		default: return launch_apply<E, 4>(a, st);
+	}
+}
+
+// q = a * inverse(r); n <= 64; z_buf: 4096 floats of scratch
+int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, const float* r, size_t ldr,
+               size_t m, size_t n, float* z_buf, hipStream_t st) {
+	const size_t NP = np_of(n);
+	const int NT = (int)(NP / 16);
+	hipLaunchKernelGGL(tsqrmi::trinv_kernel, dim3(1), dim3(64), 0, st, z_buf, r, ldr, (int)n, (int)NP);
+	HIPCHK(hipGetLastError());
+	tsqrmi::ApplyArgs aa{};
+	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = z_buf;
+	const size_t nch = cdiv(m, 64);
+	const size_t target = 4096;
+	aa.cpw = (int)std::max<size_t>(1, cdiv(nch, target));
+	aa.nchunks = (int)nch;
+	aa.nwaves = (int)cdiv(nch, (size_t)aa.cpw);
+	const int rc = (engine == 0) ? dispatch_apply_nt<0>(NT, aa, st) : dispatch_apply_nt<1>(NT, aa, st);
+	if (rc) return rc;
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+int engine_of(int mode) {
+	if (mode == TSQR_MI_FP32_NOTC) return 0;
+	if (mode == TSQR_MI_FP32_TC_COR) return 1;
+	return -1;
+}
+
+// one sweep of 64-wide-panel block QR:  (q, r) <- qr(a);  a is overwritten for n > 64; q may alias a.
+int sweep(int engine, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n,
+          float* wq, float* wr, const WqLayout& L, hipStream_t st) {
+	const size_t npanels = cdiv(n, PW);
+	for (size_t pi = 0; pi < npanels; pi++) {
+		const size_t P = pi * PW, c = std::min(PW, n - P);
+		float* ap = a + P * lda;
+		for (size_t bi = 0; bi < pi; bi++) {             // block modified Gram-Schmidt against finished panels
+			const size_t B = bi * PW;
+			const size_t rows_per_slab = 64 * std::max<size_t>(1, cdiv(cdiv(m, 64), NSLAB));
+			const int nslab = (int)cdiv(m, rows_per_slab);
+			hipLaunchKernelGGL(tsqrmi::proj_partial_kernel, dim3(nslab), dim3(256), 0, st,
+			                   wq + L.part, q + B * ldq, ldq, ap, lda, m, (int)PW, (int)c, rows_per_slab);
+			hipLaunchKernelGGL(tsqrmi::proj_reduce_kernel, dim3(16), dim3(256), 0, st,
+			                   wq + L.s, r + P * ldr + B, ldr, wq + L.part, nslab, (int)PW, (int)c);
+			hipLaunchKernelGGL(tsqrmi::update_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st,
+			                   ap, lda, q + B * ldq, ldq, wq + L.s, m, (int)PW, (int)c);
+			HIPCHK(hipGetLastError());
+		}
+		float* rpp = r + P * ldr + P;
+		int rc = fold_r(rpp, ldr, ap, lda, m, c, wq, wr, st);
+		if (rc) return rc;
+		rc = apply_rinv(engine, q + P * ldq, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsqr_mi_version(void) { return 100; }
+const char* tsqr_mi_last_error(void) { return g_last_error.c_str(); }
+
+size_t tsqr_mi_batch_size_log2(size_t m) { return ref_bs_log2(m); }
+size_t tsqr_mi_batch_size(size_t m) { return ref_bs(m); }
+
+size_t tsqr_mi_working_q_size(size_t m, size_t n) {
+	if (m == 0 || n == 0) return 0;
+	return std::max(ref_wq(m, n), wq_layout(m, n).total);
+}
+size_t tsqr_mi_working_r_size(size_t m, size_t n) {
+	if (m == 0 || n == 0) return 0;
+	size_t need = 0;
+	for (size_t P = 0; P < n; P += PW) need = std::max(need, make_plan(m, std::min(PW, n - P)).stack_a);
+	// the stack of a dist/gathered fold is tiny; nothing extra needed
+	return std::max(ref_wr(m, n), need);
+}
+size_t tsqr_mi_working_l_size(size_t m) { return m == 0 ? 0 : ref_bs(m) + 1; }
+size_t tsqr_mi_working_reorth_size(size_t m) { return 16 * 16 * 2 + m * 16; }
+
+void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave) {
+	if (level0_waves > 0) g_level0_waves = level0_waves;
+	if (tree_chunks_per_wave > 1) g_tree_cpw = tree_chunks_per_wave;
+}
+
+int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                   size_t m, size_t n, void* wq_v, void* wr_v, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
+                   void* stream) {
+	(void)reorth_w; (void)d_wl; (void)h_wl;
+	if (n > m || m == 0 || n == 0) return TSQR_MI_ERROR_INVALID_SIZE;     // reference src/blockqr.cu:409-411
+	const int engine = engine_of(mode);
+	if (engine < 0) { g_last_error = "compute_mode not implemented on gfx950"; return TSQR_MI_ERROR_UNSUPPORTED; }
+	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+	float* wq = reinterpret_cast<float*>(wq_v);
+	float* wr = reinterpret_cast<float*>(wr_v);
+	const WqLayout L = wq_layout(m, n);
+
+	int rc = sweep(engine, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, st);
+	if (rc) return rc;
+	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
+	if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, st, r, ldr, (int)n);
+	if (reorth) {
+		// second sweep on Q in place: Q <- Q * inverse(R2), R <- R2 * R   (the reference's BCGS2 plays this role)
+		float* r1 = wq + L.r1; float* r2 = wq + L.r2;
+		hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(gb), dim3(256), 0, st, r1, n, r, ldr, (int)n, (int)n);
+		HIPCHK(hipMemsetAsync(r2, 0, sizeof(float) * n * n, st));
+		rc = sweep(engine, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, st);
+		if (rc) return rc;
+		hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(st));
+	return TSQR_MI_SUCCESS;
+}
+
+int tsqr_mi_local_r_f32(float* r, size_t ldr, const float* a, size_t lda, size_t m, size_t n,
+                        void* wq, void* wr, void* stream) {
+	if (m == 0 || n == 0 || n > PW) return TSQR_MI_ERROR_INVALID_SIZE;
+	return fold_r(r, ldr, a, lda, m, n, reinterpret_cast<float*>(wq), reinterpret_cast<float*>(wr),
+	              reinterpret_cast<hipStream_t>(stream));
+}
+
+int tsqr_mi_apply_rinv_f32(int mode, float* q, size_t ldq, const float* a, size_t lda, const float* r, size_t ldr,
+                           size_t m, size_t n, void* wq, void* stream) {
+	if (m == 0 || n == 0 || n > PW) return TSQR_MI_ERROR_INVALID_SIZE;
+	const int engine = engine_of(mode);
+	if (engine < 0) return TSQR_MI_ERROR_UNSUPPORTED;
+	const WqLayout L = wq_layout(m, n);
+	return apply_rinv(engine, q, ldq, a, lda, r, ldr, m, n, reinterpret_cast<float*>(wq) + L.z,
+	                  reinterpret_cast<hipStream_t>(stream));
+}
+
+int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t n, void* wq, void* stream) {
+	if (n == 0) return TSQR_MI_ERROR_INVALID_SIZE;
+	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+	float* r1 = reinterpret_cast<float*>(wq);            // n*n floats at the start of wq
+	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
+	hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(gb), dim3(256), 0, st, r1, n, r, ldr, (int)n, (int)n);
+	hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, ldr2, r1, n, (int)n);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// ---- RCCL path: the library is resolved lazily so that libtsqr_mi.so loads without librccl ----
+typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+static nccl_allgather_t resolve_allgather() {
+	static nccl_allgather_t fn = nullptr;
+	if (!fn) {
+		void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (h) fn = reinterpret_cast<nccl_allgather_t>(dlsym(h, "ncclAllGather"));
+	}
+	return fn;
+}
+
+int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                        size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
+                        void* nccl_comm, int nranks, void* stream) {
+	if (m_local == 0 || n == 0 || n > PW || nranks < 1) return TSQR_MI_ERROR_INVALID_SIZE;
+	const int engine = engine_of(mode);
+	if (engine < 0) return TSQR_MI_ERROR_UNSUPPORTED;
+	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+	float* wq = reinterpret_cast<float*>(wq_v);
+	float* wr = reinterpret_cast<float*>(wr_v);
+	nccl_allgather_t allgather = resolve_allgather();
+	if (!allgather) { g_last_error = "librccl.so / ncclAllGather not found"; return TSQR_MI_ERROR_UNSUPPORTED; }
+	const WqLayout L = wq_layout(std::max(m_local, (size_t)nranks * n), n);
+	float* rl = wq + L.r2;                               // local R, n x n packed (ld n)
+	const float* src = a; size_t ld_src = lda;
+	for (int it = 0; it < (reorth ? 2 : 1); it++) {
+		int rc = fold_r(rl, n, src, ld_src, m_local, n, wq, wr, st);
+		if (rc) return rc;
+		// ncclFloat32 == 7 in nccl.h/rccl.h
+		if (allgather(rl, gather_buf, n * n, 7, nccl_comm, st) != 0) { g_last_error = "ncclAllGather failed"; return -1; }
+		// gather_buf is [rank][col][row]; viewed column-major with ld n it is a (nranks*n) x n stack only per rank,
+		// so fold the ranks' blocks as one tall matrix of n-row blocks: rows = nranks*n, ld = n is wrong for that ->
+		// restack into wr as a proper column-major (nranks*n) x n matrix.
+		float* stack = wr;
+		for (int k = 0; k < nranks; k++)
+			hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(16), dim3(256), 0, st,
+			                   stack + (size_t)k * n, (size_t)nranks * n, gather_buf + (size_t)k * n * n, n, (int)n, (int)n);
+		float* rdst = (it == 0) ? r : rl;
+		const size_t ldd = (it == 0) ? ldr : n;
+		rc = fold_r(rdst, ldd, stack, (size_t)nranks * n, (size_t)nranks * n, n, wq, wr + (size_t)nranks * n * n, st);
+		if (rc) return rc;
+		rc = apply_rinv(engine, q, ldq, src, ld_src, rdst, ldd, m_local, n, wq + L.z, st);
+		if (rc) return rc;
+		if (it == 1) {
+			float* r1 = wq + L.r1;
+			hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(16), dim3(256), 0, st, r1, n, r, ldr, (int)n, (int)n);
+			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(16), dim3(256), 0, st, r, ldr, rl, n, r1, n, (int)n);
+		}
+		src = q; ld_src = ldq;
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(st));
+	return TSQR_MI_SUCCESS;
+}
+
+}  // extern "C"
