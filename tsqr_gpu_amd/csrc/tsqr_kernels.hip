@@ -36,14 +36,17 @@ __device__ __forceinline__ float bcast16(float x) {
 	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + K, 0xf, 0xf, true));
 }
 
-// sum over the four lanes {c, c+16, c+32, c+48}; result in all four  (v_permlane32_swap + v_permlane16_swap)
+// sum over the four lanes {c, c+16, c+32, c+48}; result in all four  (v_permlane32_swap + v_permlane16_swap).
+// Inline asm on purpose: __builtin_amdgcn_permlane{32,16}_swap returned the same register for both results
+// under hipcc / ROCm 7.2 (sum degenerated to 2*x on MI355X; tests/test_gpu_primitives.py pins the asm form).
+// The two v_nop are the wait states a VALU write needs before v_permlane*_swap reads it.
 __device__ __forceinline__ float xq_sum(float x) {
-	const unsigned u = __builtin_bit_cast(unsigned, x);
-	const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-	const float y = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-	const unsigned v = __builtin_bit_cast(unsigned, y);
-	const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-	return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+	float a = x, b = x;
+	asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+	const float y = a + b;
+	float c = y, d = y;
+	asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+	return c + d;
 }
 
 // ---------------------------------------------------------------------------------------------

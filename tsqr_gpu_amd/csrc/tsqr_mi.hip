@@ -64,13 +64,13 @@ Plan make_plan(size_t m, size_t n) {
 	p.NP = np_of(n);
 	size_t rows = m;
 	int lv = 0;
+	// a wave turns cpw*64 source rows into NP rows: cpw*64 >= 2*NP keeps every level shrinking
+	const size_t cpw_min = std::max<size_t>(1, cdiv(2 * p.NP, 64));
 	for (;;) {
 		const size_t nch = cdiv(rows, 64);
-		size_t cpw = (lv == 0) ? std::max<size_t>(1, cdiv(nch, (size_t)g_level0_waves)) : (size_t)g_tree_cpw;
+		size_t cpw = (lv == 0) ? std::max(cpw_min, cdiv(nch, (size_t)g_level0_waves)) : std::max(cpw_min, (size_t)g_tree_cpw);
 		size_t nw = cdiv(nch, cpw);
-		if (nw <= 1) { nw = 1; cpw = nch; }
-		// a level must shrink the row count, otherwise fold everything in one wave
-		if (nw > 1 && nw * p.NP >= rows) { nw = 1; cpw = nch; }
+		if (nw <= 1 || nw * p.NP >= rows) { nw = 1; cpw = nch; }
 		p.rows[lv] = rows; p.nch[lv] = (int)nch; p.cpw[lv] = (int)cpw; p.nw[lv] = (int)nw;
 		if (nw > 1) {
 			const size_t sz = nw * p.NP * p.NP;
@@ -123,8 +123,7 @@ int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n
 	for (int lv = 0; lv < p.nlevels; lv++) {
 		tsqrmi::FoldArgs a{};
 		a.src = cur; a.ld = cur_ld; a.m = p.rows[lv];
-		a.n = (lv == 0) ? (int)n : (int)p.NP;            // stacks are NP wide (padding columns are zero)
-		if (lv > 0) a.n = (int)n;                        // ... but only the first n columns carry data
+		a.n = (int)n;                                    // stacks are NP wide, only the first n columns carry data
 		a.nchunks = p.nch[lv]; a.cpw = p.cpw[lv]; a.nwaves = p.nw[lv];
 		if (p.nw[lv] == 1) {
 			a.dst = r; a.dst_ld = ldr; a.rows_store = (int)n; a.cols_store = (int)n;
