@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the tall-skinny QR hot path (BASELINE.json: TSQR GFLOP/s and ||Q^T Q - I||_F,
+M = 2^20 x N = 64 per GPU, fp32_tc_cor).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one blocking mtk::qr::qr call (C ABI tsqr_mi_qr_f32, or the row-partitioned driver for N > 1) on a
+synthetic U(-1,1) matrix already resident in HBM.  Weak scaling: every rank owns 2^20 rows (N = 8 is BASELINE's C4,
+2^23 x 64).  For n <= 64 the engine does not modify A, so no restore is needed between steps.
+Prints ONE JSON line on rank 0 (contract in the task prompt) including `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3     # MI355X fp32 MFMA/vector peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_TBS = 8.0                 # HBM3E spec
+
+
+def f_qr(m, n):
+    """Algorithmic flops of geqrf + explicit thin Q: 4MN^2 - 4/3 N^3 (SURVEY.md 8d / BASELINE.md section 2)."""
+    return 4.0 * m * n * n - 4.0 / 3.0 * n ** 3
+
+
+def f_r(m, n):
+    return 2.0 * m * n * n - 2.0 / 3.0 * n ** 3
+
+
+def synth_block(m_local, n, m_global, row0, seed, device):
+    """U(-1,1) entries keyed by (seed, global row, column) with a splitmix64-style integer hash, so that 1/2/4/8-GPU
+    runs see the identical global matrix.  Returned as an (n, m_local) tensor = column-major m_local x n."""
+    rows = torch.arange(row0, row0 + m_local, device=device, dtype=torch.int64)
+    out = torch.empty(n, m_local, device=device, dtype=torch.float32)
+    for j in range(n):
+        x = rows + (j * m_global + seed * 1000003 + 0x632BE5AB)     # int64 arithmetic wraps; only the bit mixing matters
+        x = (x ^ (x >> 30)) * 0x1CE4E5B9
+        x = (x ^ (x >> 27)) * 0x133111EB
+        x = x ^ (x >> 31)
+        u = (x & ((1 << 24) - 1)).to(torch.float32) * (1.0 / (1 << 24))
+        out[j] = u * 2.0 - 1.0
+    return out
+
+
+def cpu_baseline(n, mode_name, sample_rows):
+    """Times the CPU oracle (restatement of the reference algorithm, oracle/ref_tsqr.c, OpenMP over leaves) and host
+    LAPACK (scipy) on a bounded sample of the same workload: sample_rows x n, U(-1,1)."""
+    from oracle import ref_oracle as ro
+    a = ro.uniform_matrix(sample_rows, n, seed=0)
+    md = ro.FP32_TC_COR if mode_name == "fp32_tc_cor" else ro.FP32_NOTC
+    ro.qr(a[:4096], md, False)
+    t = time.time()
+    st, q, r = ro.qr(a, md, False)
+    dt = time.time() - t
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    out = {"value": f_qr(sample_rows, n) / dt / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+           "sample": "oracle/ref_tsqr.c (%s, reference algorithm, OpenMP) on %d x %d U(-1,1), %.2f s; F_QR = 4MN^2 - 4/3 N^3" % (
+               mode_name, sample_rows, n, dt),
+           "orth_fro": ro.orthogonality_fro(q), "residual": ro.residual(a, q, r)}
+    try:
+        from scipy.linalg import lapack
+        af = np.asfortranarray(a)
+        t = time.time(); qr_, tau, _, info = lapack.sgeqrf(af); t_geqrf = time.time() - t
+        t = time.time(); qq, _, info = lapack.sorgqr(qr_[:, :n], tau); t_orgqr = time.time() - t
+        out["lapack"] = {"sgeqrf_gflops": f_r(sample_rows, n) / t_geqrf / 1e9,
+                         "sgeqrf_sorgqr_gflops": f_qr(sample_rows, n) / (t_geqrf + t_orgqr) / 1e9,
+                         "library": "scipy.linalg.lapack (OpenBLAS)", "cores": cores,
+                         "orth_fro": ro.orthogonality_fro(qq)}
+    except Exception as e:  # LAPACK is a reported extra, never a requirement
+        out["lapack"] = {"error": str(e)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)       # reference protocol: 1 warm-up + C = 16 calls (src/test.cu:289-309)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--m", type=int, default=1 << 20, help="rows per GPU")
+    ap.add_argument("--n", type=int, default=64)
+    ap.add_argument("--mode", default="fp32_tc_cor", choices=["fp32_tc_cor", "fp32_notc"])
+    ap.add_argument("--reorth", type=int, default=0)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from tsqr_gpu_amd import blockqr as bq
+    bq.lib()                                                # fail loudly if the HIP library is missing
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    m, n = args.m, args.n
+    m_glob = m * world
+    mode = bq.compute_mode[args.mode]
+
+    d_a = synth_block(m, n, m_glob, rank * m, 0, dev)
+    d_q = torch.empty(n, m, dtype=torch.float32, device=dev)
+    d_r = torch.zeros(n, n, dtype=torch.float32, device=dev)
+    if world == 1:
+        bf = bq.buffer(mode, bool(args.reorth), device=dev)
+        bf.allocate(m, n)
+
+        def step():
+            st = bq.qr(d_q, m, d_r, n, d_a, m, m, n, bf)
+            assert st == 0, st
+    else:
+        from tsqr_gpu_amd import dist as tdist
+        eng = tdist.HipEngine(mode, m, n, world)
+
+        def step():
+            st = tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=bool(args.reorth))
+            assert st == 0, st
+            torch.cuda.synchronize()                        # the single-GPU call is blocking; keep the same semantics
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    flops = f_qr(m_glob, n)
+    gflops = flops / (ms_per_step * 1e-3) / 1e9
+
+    # accuracy of the last step, evaluated on the device in fp64 (global Q: all-reduce of Q_p^T Q_p)
+    q64 = d_q.double()
+    gram = q64 @ q64.T
+    r64 = d_r.double().T.contiguous()
+    res_num = ((r64.T @ q64) - d_a.double()).pow(2).sum().reshape(1)
+    res_den = d_a.double().pow(2).sum().reshape(1)
+    if world > 1:
+        dist.all_reduce(gram); dist.all_reduce(res_num); dist.all_reduce(res_den)
+    orth_fro = float((gram - torch.eye(n, device=dev, dtype=torch.float64)).norm().item())
+    residual = float(torch.sqrt(res_num / res_den).item())
+    del q64
+
+    # per-kernel-class timing with HIP events on the engine's stream, same number of steps
+    prof = None
+    bq.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    barrier()
+    prof = bq.profile_read()
+    bq.profile_enable(False)
+
+    if rank == 0:
+        dom = max(prof, key=lambda k: prof[k][0])
+        dom_ms, dom_launches = prof[dom]
+        per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
+        # algorithmic work of one launch of the dominant kernel
+        if dom in ("fold_level0", "fold_tree"):
+            alg_flops = f_r(m, n)                           # R factor of the local block: 2MN^2 - 2/3 N^3
+            alg_bytes = 4.0 * m * n
+        else:
+            alg_flops = 2.0 * m * n * n                     # Q = A * inverse(R)
+            alg_bytes = 8.0 * m * n
+        ach = alg_flops / per_launch_s / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                    "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
+                    "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                    "hbm_gbs": alg_bytes / per_launch_s / 1e9,
+                    "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+                    "whole_path": {"tflops": gflops / 1e3 / world, "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
+                                   "algorithmic_gbs": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e9,
+                                   "frac_hbm_peak": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e12 / PEAK_HBM_TBS}}
+        out = {"metric": "tsqr_gflops", "value": gflops, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32" if args.mode == "fp32_notc" else "f32 (bf16x3-split MFMA, f32 accumulate)",
+               "data": "synthetic",
+               "config": {"workload": "M=2^%d x N=%d per GPU, %s, reorth=%d, U(-1,1); global %d x %d; F_QR=4MN^2-4/3N^3" % (
+                   int(np.log2(m)) if m & (m - 1) == 0 else -1, n, args.mode, args.reorth, m_glob, n),
+                   "m_per_gpu": m, "n": n, "mode": args.mode, "reorthogonalize": bool(args.reorth),
+                   "parallelism": "row-partitioned x%d" % world},
+               "orth_fro": orth_fro, "orth_ref_metric": orth_fro / np.sqrt(n), "residual": residual,
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.mode, args.cpu_sample_rows)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+// blockqr.hpp -- MI355X-native replacement for the reference header of the same name.
+//
+// Keeps the public surface of reference src/blockqr.hpp (mtk::qr::compute_mode :12-23, tsqr_colmun_size :25,
+// state_t :27-29, get_working_*_size :55-57, buffer :59-140, qr :142-175) so that callers written against
+// enp1s0/tsqr-gpu compile unchanged, except for ONE argument: the reference passes a cublasHandle_t, which it
+// uses only to obtain the stream (src/blockqr.cu:58-59) and to run its inter-panel GEMMs.  There is no cuBLAS on
+// ROCm and no compatibility shim here; the last argument is a hipStream_t (mtk::qr::handle_t).  Overloads
+// without the handle use the null stream.
+//
+// Header-only: everything forwards to the extern "C" ABI of libtsqr_mi.so (include/tsqr_mi.h).
+// Link with -ltsqr_mi.
+#ifndef __BLOCKQR_HPP__
+#define __BLOCKQR_HPP__
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include "../tsqr_mi.h"
+
+namespace mtk {
+namespace tsqr {
+// reference src/tsqr.cu:39-44
+inline std::size_t get_batch_size_log2(const std::size_t m) { return tsqr_mi_batch_size_log2(m); }
+inline std::size_t get_batch_size(const std::size_t m) { return tsqr_mi_batch_size(m); }
+}  // namespace tsqr
+
+namespace qr {
+
+enum compute_mode {
+	fp16_notc,
+	fp16_tc_nocor,
+	fp32_notc,
+	fp32_tc_cor,
+	fp32_tc_nocor,
+	mixed_tc_cor_emu,
+	tf32_tc_cor,
+	tf32_tc_cor_emu,
+	tf32_tc_nocor,
+	tf32_tc_nocor_emu,
+};
+
+constexpr std::size_t tsqr_colmun_size = 16;
+
+using state_t = int;
+const state_t success_factorization = 0;
+const state_t error_invalid_matrix_size = 1;
+const state_t error_unsupported_mode = 2;      // new: compute_mode without a gfx950 implementation
+
+using handle_t = hipStream_t;                  // takes the place of cublasHandle_t (see the header comment)
+
+// Element types.  Only the fp32 I/O modes are implemented on gfx950; their io / working types are float,
+// as in reference src/tsqr.hpp:25-39 (the half-typed modes are declared so that code naming them still
+// compiles; calling them returns error_unsupported_mode).
+template <mtk::qr::compute_mode mode> struct get_working_q_type { using type = float; };
+template <mtk::qr::compute_mode mode> struct get_working_r_type { using type = float; };
+template <mtk::qr::compute_mode mode> struct get_io_type { using type = float; };
+
+// get working memory size (element counts), reference src/blockqr.hpp:55-57
+inline std::size_t get_working_q_size(const std::size_t m, const std::size_t n) { return tsqr_mi_working_q_size(m, n); }
+inline std::size_t get_working_r_size(const std::size_t m, const std::size_t n) { return tsqr_mi_working_r_size(m, n); }
+inline std::size_t get_working_l_size(const std::size_t m) { return tsqr_mi_working_l_size(m); }
+
+namespace detail {
+inline void check(hipError_t e, const char* what) {
+	if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+}  // namespace detail
+
+template <mtk::qr::compute_mode mode, bool Reorthogonalize>
+struct buffer {
+	typename get_working_q_type<mode>::type* dwq;
+	typename get_working_r_type<mode>::type* dwr;
+	typename get_io_type<mode>::type* dw_reorth_r;
+	unsigned* dl;
+	unsigned* hl;
+
+	std::size_t total_memory_size;
+
+	buffer() : dwq(nullptr), dwr(nullptr), dw_reorth_r(nullptr), dl(nullptr), hl(nullptr), total_memory_size(0lu) {}
+	~buffer() { destroy(); }
+	buffer(const buffer&) = delete;
+	buffer& operator=(const buffer&) = delete;
+
+	void allocate(const std::size_t m, const std::size_t n) {
+		if (dwq != nullptr || dwr != nullptr || dl != nullptr || hl != nullptr) {
+			throw std::runtime_error("The buffer has been already allocated");
+		}
+		const auto wq_size = sizeof(typename get_working_q_type<mode>::type) * get_working_q_size(m, n);
+		const auto wr_size = sizeof(typename get_working_r_type<mode>::type) * get_working_r_size(m, n);
+		const auto l_size = sizeof(unsigned) * get_working_l_size(m);
+		detail::check(hipMalloc(reinterpret_cast<void**>(&dwq), wq_size), "hipMalloc(dwq)");
+		detail::check(hipMalloc(reinterpret_cast<void**>(&dwr), wr_size), "hipMalloc(dwr)");
+		detail::check(hipMalloc(reinterpret_cast<void**>(&dl), l_size), "hipMalloc(dl)");
+		detail::check(hipHostMalloc(reinterpret_cast<void**>(&hl), l_size), "hipHostMalloc(hl)");
+		total_memory_size = wq_size + wr_size + l_size;
+		if (Reorthogonalize) {
+			const auto reorth_r_size = sizeof(typename get_io_type<mode>::type) * tsqr_mi_working_reorth_size(m);
+			detail::check(hipMalloc(reinterpret_cast<void**>(&dw_reorth_r), reorth_r_size), "hipMalloc(dw_reorth_r)");
+			total_memory_size += reorth_r_size;
+		}
+	}
+
+	void destroy() {
+		if (dwq) (void)hipFree(dwq);
+		dwq = nullptr;
+		if (dwr) (void)hipFree(dwr);
+		dwr = nullptr;
+		if (dw_reorth_r) (void)hipFree(dw_reorth_r);
+		dw_reorth_r = nullptr;
+		if (dl) (void)hipFree(dl);
+		dl = nullptr;
+		if (hl) (void)hipHostFree(hl);
+		hl = nullptr;
+	}
+
+	// host-resident variants of the reference (src/blockqr.hpp:97-135): pinned host memory mapped to the device
+	void allocate_host(const std::size_t m, const std::size_t n) {
+		if (dwq != nullptr || dwr != nullptr || dl != nullptr || hl != nullptr) {
+			throw std::runtime_error("The buffer has been already allocated");
+		}
+		const auto wq_size = sizeof(typename get_working_q_type<mode>::type) * get_working_q_size(m, n);
+		const auto wr_size = sizeof(typename get_working_r_type<mode>::type) * get_working_r_size(m, n);
+		const auto l_size = sizeof(unsigned) * get_working_l_size(m);
+		detail::check(hipHostMalloc(reinterpret_cast<void**>(&dwq), wq_size), "hipHostMalloc(dwq)");
+		detail::check(hipHostMalloc(reinterpret_cast<void**>(&dwr), wr_size), "hipHostMalloc(dwr)");
+		detail::check(hipHostMalloc(reinterpret_cast<void**>(&dl), l_size), "hipHostMalloc(dl)");
+		detail::check(hipHostMalloc(reinterpret_cast<void**>(&hl), l_size), "hipHostMalloc(hl)");
+		total_memory_size = wq_size + wr_size + l_size;
+		if (Reorthogonalize) {
+			const auto reorth_r_size = sizeof(typename get_io_type<mode>::type) * tsqr_mi_working_reorth_size(m);
+			detail::check(hipHostMalloc(reinterpret_cast<void**>(&dw_reorth_r), reorth_r_size), "hipHostMalloc(dw_reorth_r)");
+			total_memory_size += reorth_r_size;
+		}
+	}
+
+	void destroy_host() {
+		if (dwq) (void)hipHostFree(dwq);
+		dwq = nullptr;
+		if (dwr) (void)hipHostFree(dwr);
+		dwr = nullptr;
+		if (dw_reorth_r) (void)hipHostFree(dw_reorth_r);
+		dw_reorth_r = nullptr;
+		if (dl) (void)hipHostFree(dl);
+		dl = nullptr;
+		if (hl) (void)hipHostFree(hl);
+		hl = nullptr;
+	}
+
+	std::size_t get_device_memory_size() const { return total_memory_size; }
+};
+
+// reference src/blockqr.hpp:142-154 / src/blockqr.cu:394-433.  Blocking; returns state_t; runtime failures throw
+// std::runtime_error (the reference throws from CUTF_CHECK_ERROR).
+template <mtk::qr::compute_mode mode, bool Reorthogonalize>
+inline state_t qr(
+		typename mtk::qr::get_io_type<mode>::type* const q_ptr, const std::size_t ldq,
+		typename mtk::qr::get_io_type<mode>::type* const r_ptr, const std::size_t ldr,
+		typename mtk::qr::get_io_type<mode>::type* const a_ptr, const std::size_t lda,
+		const std::size_t m, const std::size_t n,
+		typename mtk::qr::get_working_q_type<mode>::type* const wq_ptr,
+		typename mtk::qr::get_working_r_type<mode>::type* const wr_ptr,
+		typename mtk::qr::get_io_type<mode>::type* const reorth_r_ptr,
+		unsigned* const d_wl_ptr,
+		unsigned* const h_wl_ptr,
+		handle_t const stream = nullptr) {
+	const int st = tsqr_mi_qr_f32(static_cast<int>(mode), Reorthogonalize ? 1 : 0,
+	                              q_ptr, ldq, r_ptr, ldr, a_ptr, lda, m, n,
+	                              wq_ptr, wr_ptr, reorth_r_ptr, d_wl_ptr, h_wl_ptr, stream);
+	if (st < 0) throw std::runtime_error(std::string("mtk::qr::qr: ") + tsqr_mi_last_error());
+	return st;
+}
+
+// reference src/blockqr.hpp:155-175
+template <mtk::qr::compute_mode mode, bool Reorthogonalize>
+inline state_t qr(
+		typename mtk::qr::get_io_type<mode>::type* const q_ptr, const std::size_t ldq,
+		typename mtk::qr::get_io_type<mode>::type* const r_ptr, const std::size_t ldr,
+		typename mtk::qr::get_io_type<mode>::type* const a_ptr, const std::size_t lda,
+		const std::size_t m, const std::size_t n,
+		buffer<mode, Reorthogonalize>& bf,
+		handle_t const stream = nullptr) {
+	return qr<mode, Reorthogonalize>(
+			q_ptr, ldq,
+			r_ptr, ldr,
+			a_ptr, lda,
+			m, n,
+			bf.dwq,
+			bf.dwr,
+			bf.dw_reorth_r,
+			bf.dl,
+			bf.hl,
+			stream
+			);
+}
+}  // namespace qr
+}  // namespace mtk
+
+#endif /* end of include guard */

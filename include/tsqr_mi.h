@@ -89,6 +89,13 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth,
                         void* wq, void* wr, float* gather_buf /* nranks*n*n floats */,
                         void* nccl_comm, int nranks, void* stream);
 
+/* Optional timing of the engine's kernels with HIP events recorded on the caller's stream.  Classes:
+ * 0 first fold level (streams A), 1 fold-tree levels, 2 triangular inverse, 3 apply (Q = A*inverse(R)),
+ * 4 inter-panel coupling (n > 64), 5 other.  read() returns accumulated milliseconds and launch counts
+ * since enable(1); call it after the blocking qr call(s). */
+void tsqr_mi_profile_enable(int on);
+int tsqr_mi_profile_read(double* ms, long* launches, int max_classes);
+
 /* tuning knobs (0 = keep default): waves targeted by the first fold level, chunks folded per wave on tree levels */
 void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave);
 

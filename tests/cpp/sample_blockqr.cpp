@@ -1,0 +1,67 @@
+// The reference README's sample (README.md:52-87) written against include/tsqr/blockqr.hpp: shows that a caller
+// of mtk::qr::qr<mode, Reorth>() / mtk::qr::buffer switches by changing the handle argument only.
+// Prints residual and orthogonality; exit code 0 when both are within tolerance.
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include <tsqr/blockqr.hpp>
+
+template <mtk::qr::compute_mode compute_mode, bool reorthogonalize>
+int run(const std::size_t M, const std::size_t N) {
+	using compute_t = float;
+	std::mt19937 mt(0);
+	std::uniform_real_distribution<float> dist(-1.0f, 1.0f);
+	std::vector<compute_t> h_a(M * N), h_q(M * N), h_r(N * N, 0.0f);
+	for (auto& v : h_a) v = dist(mt);
+
+	compute_t *d_a, *d_r, *d_q;
+	hipMalloc((void**)&d_a, sizeof(compute_t) * M * N);
+	hipMalloc((void**)&d_r, sizeof(compute_t) * N * N);
+	hipMalloc((void**)&d_q, sizeof(compute_t) * M * N);
+	hipMemcpy(d_a, h_a.data(), sizeof(compute_t) * M * N, hipMemcpyHostToDevice);
+	hipMemset(d_r, 0, sizeof(compute_t) * N * N);
+
+	mtk::qr::buffer<compute_mode, reorthogonalize> buffer;
+	buffer.allocate(M, N);
+	bool threw = false;
+	try { buffer.allocate(M, N); } catch (const std::runtime_error&) { threw = true; }   // reference blockqr.hpp:77-79
+
+	hipStream_t stream;
+	hipStreamCreate(&stream);
+	const auto st = mtk::qr::qr<compute_mode, reorthogonalize>(d_q, M, d_r, N, d_a, M, M, N, buffer, stream);
+	hipMemcpy(h_q.data(), d_q, sizeof(compute_t) * M * N, hipMemcpyDeviceToHost);
+	hipMemcpy(h_r.data(), d_r, sizeof(compute_t) * N * N, hipMemcpyDeviceToHost);
+
+	double num = 0, den = 0, orth = 0;
+	for (std::size_t j = 0; j < N; j++)
+		for (std::size_t i = 0; i < M; i++) {
+			double s = 0;
+			for (std::size_t k = 0; k <= j; k++) s += (double)h_q[i + k * M] * h_r[k + j * N];
+			const double d = s - h_a[i + j * M];
+			num += d * d; den += (double)h_a[i + j * M] * h_a[i + j * M];
+		}
+	for (std::size_t a = 0; a < N; a++)
+		for (std::size_t b = 0; b < N; b++) {
+			double s = 0;
+			for (std::size_t i = 0; i < M; i++) s += (double)h_q[i + a * M] * h_q[i + b * M];
+			s -= (a == b);
+			orth += s * s;
+		}
+	const double residual = std::sqrt(num / den), orthogonality = std::sqrt(orth);
+	std::printf("mode=%d reorth=%d state=%d residual=%e orthogonality_F=%e double_allocate_threw=%d bytes=%zu\n",
+	            (int)compute_mode, (int)reorthogonalize, st, residual, orthogonality, (int)threw, buffer.get_device_memory_size());
+	const auto bad = mtk::qr::qr<compute_mode, reorthogonalize>(d_q, N, d_r, M, d_a, N, N, M, buffer, stream);   // n > m
+	hipFree(d_a); hipFree(d_r); hipFree(d_q); hipStreamDestroy(stream);
+	return (st == mtk::qr::success_factorization && bad == mtk::qr::error_invalid_matrix_size && threw &&
+	        residual < 5e-7 && orthogonality < 5e-6) ? 0 : 1;
+}
+
+int main() {
+	int rc = 0;
+	rc |= run<mtk::qr::compute_mode::fp32_tc_cor, false>(9211, 51);
+	rc |= run<mtk::qr::compute_mode::fp32_notc, false>(9211, 51);
+	rc |= run<mtk::qr::compute_mode::fp32_tc_cor, true>(2000, 100);
+	std::printf(rc == 0 ? "SAMPLE OK\n" : "SAMPLE FAILED\n");
+	return rc;
+}

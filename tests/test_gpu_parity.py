@@ -1,0 +1,185 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the oracle.
+
+Floating-point path -> tolerance-based parity (north_star: match the reference's fp32_notc / fp32_tc_cor outputs
+within a stated ||A-QR||/||A|| and ||Q^T Q - I|| tolerance on identical inputs):
+  * residual  ||A-QR||_F/||A||_F  <= 5e-7 (the oracle itself reaches 1e-6 / 2.5e-6)
+  * ||Q^T Q - I||_F               <= 5e-6 for cond(A) < 10 (oracle: 3e-6 / 1e-5); scaled by cond(A) otherwise
+  * sign-normalised R and Q agree with the oracle's to 2e-5 * cond(A) (relative to max|R|, absolute for Q)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RES_TOL = 5e-7
+ORTH_TOL = 5e-6
+PAR_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def run_gpu(bq, torch, a, mode, reorth, lda_pad=0, ldq_pad=0):
+    m, n = a.shape
+    lda, ldq = m + lda_pad, m + ldq_pad
+    buf = np.zeros((n, lda), np.float32)
+    buf[:, :m] = a.T
+    d_a = torch.from_numpy(buf).cuda()
+    d_q = torch.full((n, ldq), float("nan"), dtype=torch.float32, device="cuda")
+    d_r = torch.zeros(n, n, dtype=torch.float32, device="cuda")      # caller pre-zeros R (reference src/test.cu:129)
+    bf = bq.buffer(mode, reorth)
+    bf.allocate(m, n)
+    st = bq.qr(d_q, ldq, d_r, n, d_a, lda, m, n, bf)
+    q_full = d_q.cpu().numpy()
+    if ldq_pad:
+        assert np.isnan(q_full[:, m:]).all(), "wrote outside the m x n block of Q"
+    return st, q_full[:, :m].T.copy(), d_r.cpu().numpy().T.copy()
+
+
+CASES = [(128, 16), (64, 16), (33, 16), (32, 16), (20, 7), (17, 17), (100, 7), (200, 40), (1000, 64), (4096, 64),
+         (9211, 51), (4097, 33), (65536, 64), (4096, 128), (9000, 100), (5000, 200)]
+
+
+@pytest.mark.parametrize("m,n", CASES)
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+def test_parity_with_oracle(bq, oracle, torch_cuda, m, n, mode):
+    md = bq.compute_mode[mode]
+    a = oracle.uniform_matrix(m, n, seed=11)
+    cond = np.linalg.cond(a.astype(np.float64))
+    st, q, r = run_gpu(bq, torch_cuda, a, md, False, lda_pad=(5 if m % 2 else 0), ldq_pad=3)
+    assert st == bq.success_factorization
+    assert np.isfinite(q).all() and np.isfinite(r).all()
+    assert np.abs(np.tril(r, -1)).max() == 0.0                      # exact zeros below the diagonal
+    assert oracle.residual(a, q, r) < RES_TOL
+    assert oracle.orthogonality_fro(q) < ORTH_TOL * max(1.0, cond / 10)
+    st_o, q_o, r_o = oracle.qr(a, int(md), False)
+    assert st_o == 0
+    qn, rn = oracle.sign_normalise(q, r)
+    qon, ron = oracle.sign_normalise(q_o, np.triu(r_o))
+    scale = max(1.0, cond / 10)
+    assert np.abs(rn - ron).max() / np.abs(ron).max() < PAR_TOL * scale
+    assert np.abs(qn - qon).max() < PAR_TOL * scale
+
+
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+def test_golden_fixtures(bq, oracle, torch_cuda, mode):
+    import json, os
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    for case in json.load(open(os.path.join(G, "golden.json")))["cases"]:
+        data = np.load(os.path.join(G, case["file"]))
+        a = oracle.uniform_matrix(case["m"], case["n"], seed=case["seed"])
+        st, q, r = run_gpu(bq, torch_cuda, a, bq.compute_mode[mode], False)
+        assert st == 0
+        absr = np.abs(r)
+        assert np.allclose(absr, data["absr_lapack64"], rtol=0, atol=5e-6 * absr.max())
+        assert np.allclose(absr, data["absr_" + mode], rtol=0, atol=2e-5 * absr.max())
+        assert oracle.residual(a, q, r) < case["residual_max"][mode]
+        assert oracle.orthogonality_fro(q) < case["orth_fro_max"][mode]
+
+
+@pytest.mark.parametrize("cond", [1e2, 1e4, 2.0 ** 15, 1e8])
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+def test_ill_conditioned_reorth(bq, oracle, torch_cuda, cond, mode):
+    """latms-style inputs (reference src/test_cond.cu:20-76); Reorthogonalize=true must give O(eps) orthogonality,
+    never worse than the oracle's BCGS2; without it the loss may grow like cond*eps but the residual stays small."""
+    a = oracle.matrix_with_cond(1 << 14, 64, cond, seed=5)
+    md = bq.compute_mode[mode]
+    st, q, r = run_gpu(bq, torch_cuda, a, md, True)
+    assert st == 0
+    assert oracle.residual(a, q, r) < 2e-6
+    orth = oracle.orthogonality_fro(q)
+    assert orth < 1e-5
+    _, q_o, r_o = oracle.qr(a, int(md), True)
+    assert orth < 3 * max(oracle.orthogonality_fro(q_o), 2e-6)
+    st, q0, r0 = run_gpu(bq, torch_cuda, a, md, False)
+    assert oracle.residual(a, q0, r0) < 2e-6
+    assert oracle.orthogonality_fro(q0) < max(1e-5, 1e-6 * cond) or cond >= 1e7
+    _, q_o0, _ = oracle.qr(a, int(md), False)
+    if cond <= 2.0 ** 15:       # the reference's own sweep range (src/main.cu:104-111): never worse than the oracle
+        assert oracle.orthogonality_fro(q0) < 3 * max(oracle.orthogonality_fro(q_o0), 2e-6)
+
+
+def test_error_codes_on_gpu(bq, torch_cuda):
+    torch = torch_cuda
+    t = torch.zeros(64, device="cuda")
+    bf = bq.buffer(bq.compute_mode.fp32_tc_cor, False)
+    bf.allocate(8, 4)
+    assert bq.qr(t, 4, t, 8, t, 4, 4, 8, bf) == bq.error_invalid_matrix_size
+    assert bq.qr(t, 1, t, 1, t, 1, 0, 0, bf) == bq.error_invalid_matrix_size
+    assert bq.qr(t, 8, t, 4, t, 8, 8, 4, bf, mode=bq.compute_mode.tf32_tc_cor) == bq.error_unsupported_mode
+    with pytest.raises(RuntimeError):
+        bf.allocate(8, 4)                                            # reference src/blockqr.hpp:77-79
+
+
+def test_input_not_clobbered_for_single_panel(bq, oracle, torch_cuda):
+    torch = torch_cuda
+    m, n = 3000, 64
+    a = oracle.uniform_matrix(m, n, seed=2)
+    d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+    bf = bq.buffer(bq.compute_mode.fp32_tc_cor, False); bf.allocate(m, n)
+    bq.qr(d_q, m, d_r, n, d_a, m, m, n, bf)
+    assert np.array_equal(d_a.cpu().numpy().T, a)
+
+
+def test_inplace_q_aliases_a(bq, oracle, torch_cuda):
+    # the reference's BCGS2 calls tsqr16 with q == a (src/blockqr.cu:297-307); the engine supports the same aliasing
+    torch = torch_cuda
+    m, n = 5000, 48
+    a = oracle.uniform_matrix(m, n, seed=4)
+    d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    d_r = torch.zeros(n, n, device="cuda")
+    bf = bq.buffer(bq.compute_mode.fp32_notc, False); bf.allocate(m, n)
+    assert bq.qr(d_a, m, d_r, n, d_a, m, m, n, bf) == 0
+    q = d_a.cpu().numpy().T; r = d_r.cpu().numpy().T
+    assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL
+
+
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+def test_full_size_properties(bq, oracle, torch_cuda, mode):
+    """BASELINE.json C2 at full size (2^20 x 64): size-independent properties evaluated on the device in fp64 --
+    orthogonality, residual, R upper triangular, idempotence (qr(Q) gives R2 = +-I)."""
+    torch = torch_cuda
+    m, n = 1 << 20, 64
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    d_a = (torch.rand(n, m, generator=g, device="cuda", dtype=torch.float32) * 2 - 1)
+    d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+    bf = bq.buffer(bq.compute_mode[mode], False); bf.allocate(m, n)
+    assert bq.qr(d_q, m, d_r, n, d_a, m, m, n, bf) == 0
+    q64 = d_q.double()                                               # (n, m) = Q^T
+    gram = q64 @ q64.T - torch.eye(n, device="cuda", dtype=torch.float64)
+    assert gram.norm().item() < 1e-5                                 # north_star: ||Q^T Q - I||_F < 1e-5
+    r64 = d_r.double().T.contiguous()                                # R (n x n)
+    resid = (r64.T @ q64 - d_a.double()).norm().item() / d_a.double().norm().item()
+    assert resid < RES_TOL
+    assert torch.tril(d_r.T, -1).abs().max().item() == 0.0
+    d_r2 = torch.zeros(n, n, device="cuda"); d_q2 = torch.empty(n, m, device="cuda")
+    assert bq.qr(d_q2, m, d_r2, n, d_q, m, m, n, bf) == 0
+    assert (d_r2.T.abs() - torch.eye(n, device="cuda")).abs().max().item() < 5e-6
+
+
+def test_scaling_linearity(bq, oracle, torch_cuda):
+    # qr(s*A) = (Q, s*R) for a power of two s: exact in every engine (bf16 split keeps the fp32 exponent range)
+    m, n = 6000, 64
+    a = oracle.uniform_matrix(m, n, seed=9)
+    for mode in (bq.compute_mode.fp32_notc, bq.compute_mode.fp32_tc_cor):
+        _, q1, r1 = run_gpu(bq, torch_cuda, a, mode, False)
+        for s in (2.0 ** -20, 2.0 ** 12):
+            _, q2, r2 = run_gpu(bq, torch_cuda, (a * s).astype(np.float32), mode, False)
+            assert np.array_equal(r2, (r1 * s).astype(np.float32))
+            assert np.array_equal(q2, q1)
+
+
+def test_cpp_sample_through_header(bq, torch_cuda):
+    """The reference README's sample, written against include/tsqr/blockqr.hpp (prebuilt by the CPU check)."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "sample_blockqr")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0 and "SAMPLE OK" in out.stdout, out.stdout + out.stderr

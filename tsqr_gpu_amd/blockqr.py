@@ -41,7 +41,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_working_q_size", "tsqr_mi_working_r_size", "tsqr_mi_working_l_size",
     "tsqr_mi_working_reorth_size", "tsqr_mi_batch_size_log2", "tsqr_mi_batch_size",
     "tsqr_mi_qr_f32", "tsqr_mi_local_r_f32", "tsqr_mi_apply_rinv_f32", "tsqr_mi_rmul_f32",
-    "tsqr_mi_qr_f32_dist", "tsqr_mi_set_tuning",
+    "tsqr_mi_qr_f32_dist", "tsqr_mi_set_tuning", "tsqr_mi_profile_enable", "tsqr_mi_profile_read",
 ]
 
 _lib = None
@@ -75,6 +75,10 @@ def lib():
     L.tsqr_mi_rmul_f32.argtypes = [vp, sz, vp, sz, sz, vp, vp]
     L.tsqr_mi_qr_f32_dist.restype = ci
     L.tsqr_mi_qr_f32_dist.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, ci, vp]
+    L.tsqr_mi_profile_enable.restype = None
+    L.tsqr_mi_profile_enable.argtypes = [ci]
+    L.tsqr_mi_profile_read.restype = ci
+    L.tsqr_mi_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ci]
     L.tsqr_mi_set_tuning.restype = None
     L.tsqr_mi_set_tuning.argtypes = [ci, ci]
     _lib = L
@@ -170,3 +174,18 @@ def qr(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize
 
 def set_tuning(level0_waves=0, tree_chunks_per_wave=0):
     lib().tsqr_mi_set_tuning(level0_waves, tree_chunks_per_wave)
+
+
+KERNEL_CLASSES = ["fold_level0", "fold_tree", "trinv", "apply", "coupling", "other"]
+
+
+def profile_enable(on=True):
+    lib().tsqr_mi_profile_enable(int(bool(on)))
+
+
+def profile_read():
+    """{class: (milliseconds, launches)} accumulated since profile_enable(True)."""
+    ms = (ctypes.c_double * 6)()
+    cnt = (ctypes.c_long * 6)()
+    k = lib().tsqr_mi_profile_read(ms, cnt, 6)
+    return {KERNEL_CLASSES[i]: (ms[i], cnt[i]) for i in range(k)}

@@ -28,6 +28,40 @@ thread_local std::string g_last_error;
 int g_level0_waves = 2048;
 int g_tree_cpw = 4;
 
+// ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
+enum { KC_FOLD0 = 0, KC_TREE = 1, KC_TRINV = 2, KC_APPLY = 3, KC_COUPLE = 4, KC_MISC = 5, KC_COUNT = 6 };
+struct Prof {
+	bool on = false;
+	static constexpr int MAXEV = 4096;
+	hipEvent_t ev[2 * MAXEV];
+	int cls[MAXEV];
+	int n = 0;
+	bool created = false;
+	double ms[KC_COUNT] = {0, 0, 0, 0, 0, 0};
+	long launches[KC_COUNT] = {0, 0, 0, 0, 0, 0};
+} g_prof;
+struct ProfScope {                 // brackets one kernel launch (or a short launch group) with two events
+	int idx = -1; hipStream_t st;
+	ProfScope(int kc, hipStream_t s) : st(s) {
+		if (g_prof.on && g_prof.n < Prof::MAXEV) {
+			idx = g_prof.n++;
+			g_prof.cls[idx] = kc;
+			(void)hipEventRecord(g_prof.ev[2 * idx], st);
+		}
+	}
+	~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.ev[2 * idx + 1], st); }
+};
+void prof_collect() {              // after the stream is idle
+	for (int i = 0; i < g_prof.n; i++) {
+		float t = 0.0f;
+		if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) == hipSuccess) {
+			g_prof.ms[g_prof.cls[i]] += t;
+			g_prof.launches[g_prof.cls[i]] += 1;
+		}
+	}
+	g_prof.n = 0;
+}
+
 constexpr size_t PW = 64;          // panel width
 constexpr int NSLAB = 512;         // row slabs of the projection kernel
 
@@ -132,7 +166,10 @@ int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n
 			a.dst = stack; a.dst_ld = (size_t)p.nw[lv] * p.NP; a.rows_store = (int)p.NP; a.cols_store = (int)p.NP;
 			cur = stack; cur_ld = a.dst_ld;
 		}
-		dispatch_fold(NT, a, st);
+		{
+			ProfScope ps(lv == 0 ? KC_FOLD0 : KC_TREE, st);
+			dispatch_fold(NT, a, st);
+		}
 		HIPCHK(hipGetLastError());
 	}
 	return 0;
@@ -165,7 +202,10 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
                size_t m, size_t n, float* z_buf, hipStream_t st) {
 	const size_t NP = np_of(n);
 	const int NT = (int)(NP / 16);
-	hipLaunchKernelGGL(tsqrmi::trinv_kernel, dim3(1), dim3(64), 0, st, z_buf, r, ldr, (int)n, (int)NP);
+	{
+		ProfScope ps(KC_TRINV, st);
+		hipLaunchKernelGGL(tsqrmi::trinv_kernel, dim3(1), dim3(64), 0, st, z_buf, r, ldr, (int)n, (int)NP);
+	}
 	HIPCHK(hipGetLastError());
 	tsqrmi::ApplyArgs aa{};
 	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = z_buf;
@@ -174,7 +214,11 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
 	aa.cpw = (int)std::max<size_t>(1, cdiv(nch, target));
 	aa.nchunks = (int)nch;
 	aa.nwaves = (int)cdiv(nch, (size_t)aa.cpw);
-	const int rc = (engine == 0) ? dispatch_apply_nt<0>(NT, aa, st) : dispatch_apply_nt<1>(NT, aa, st);
+	int rc;
+	{
+		ProfScope ps(KC_APPLY, st);
+		rc = (engine == 0) ? dispatch_apply_nt<0>(NT, aa, st) : dispatch_apply_nt<1>(NT, aa, st);
+	}
 	if (rc) return rc;
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -197,6 +241,7 @@ int sweep(int engine, float* q, size_t ldq, float* r, size_t ldr, float* a, size
 			const size_t B = bi * PW;
 			const size_t rows_per_slab = 64 * std::max<size_t>(1, cdiv(cdiv(m, 64), NSLAB));
 			const int nslab = (int)cdiv(m, rows_per_slab);
+			ProfScope ps(KC_COUPLE, st);
 			hipLaunchKernelGGL(tsqrmi::proj_partial_kernel, dim3(nslab), dim3(256), 0, st,
 			                   wq + L.part, q + B * ldq, ldq, ap, lda, m, (int)PW, (int)c, rows_per_slab);
 			hipLaunchKernelGGL(tsqrmi::proj_reduce_kernel, dim3(16), dim3(256), 0, st,
@@ -238,6 +283,22 @@ size_t tsqr_mi_working_r_size(size_t m, size_t n) {
 size_t tsqr_mi_working_l_size(size_t m) { return m == 0 ? 0 : ref_bs(m) + 1; }
 size_t tsqr_mi_working_reorth_size(size_t m) { return 16 * 16 * 2 + m * 16; }
 
+void tsqr_mi_profile_enable(int on) {
+	if (on && !g_prof.created) {
+		for (int i = 0; i < 2 * Prof::MAXEV; i++) (void)hipEventCreate(&g_prof.ev[i]);
+		g_prof.created = true;
+	}
+	g_prof.on = on != 0;
+	g_prof.n = 0;
+	for (int k = 0; k < KC_COUNT; k++) { g_prof.ms[k] = 0; g_prof.launches[k] = 0; }
+}
+int tsqr_mi_profile_read(double* ms, long* launches, int max_classes) {
+	prof_collect();
+	const int k = std::min(max_classes, (int)KC_COUNT);
+	for (int i = 0; i < k; i++) { ms[i] = g_prof.ms[i]; launches[i] = g_prof.launches[i]; }
+	return k;
+}
+
 void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave) {
 	if (level0_waves > 0) g_level0_waves = level0_waves;
 	if (tree_chunks_per_wave > 1) g_tree_cpw = tree_chunks_per_wave;
@@ -270,6 +331,7 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(st));
+	prof_collect();
 	return TSQR_MI_SUCCESS;
 }
 
