@@ -91,10 +91,18 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth,
 
 /* Optional timing of the engine's kernels with HIP events recorded on the caller's stream.  Classes:
  * 0 first fold level (streams A), 1 fold-tree levels, 2 triangular inverse, 3 apply (Q = A*inverse(R)),
- * 4 inter-panel coupling (n > 64), 5 other.  read() returns accumulated milliseconds and launch counts
+ * 4 inter-panel coupling (n > 64), 5 other, 6 Gram matrix, 7 Gram reduction + Cholesky + inverse.  read() returns accumulated milliseconds and launch counts
  * since enable(1); call it after the blocking qr call(s). */
 void tsqr_mi_profile_enable(int on);
 int tsqr_mi_profile_read(double* ms, long* launches, int max_classes);
+
+/* R-factor engine policy.  0 (default) auto: fp32_tc_cor uses the Gram engine (G = A^T A on the fp64 matrix cores,
+ * R = chol(G) in fp64) and falls back to the Householder TSQR engine when the Cholesky factorisation reports
+ * breakdown (cond(A) beyond ~1e6); fp32_notc always uses Householder TSQR (fp32 arithmetic only).
+ * 1: always Householder TSQR.  2: always Gram (no fallback; for tests).
+ * tsqr_mi_last_engine(): engine of the last tsqr_mi_qr_f32 call: 0 Householder, 1 Gram, 2 Gram broke down -> Householder. */
+void tsqr_mi_set_policy(int policy);
+int tsqr_mi_last_engine(void);
 
 /* tuning knobs (0 = keep default): waves targeted by the first fold level, chunks folded per wave on tree levels */
 void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave);

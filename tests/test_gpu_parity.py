@@ -183,3 +183,40 @@ def test_cpp_sample_through_header(bq, torch_cuda):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0 and "SAMPLE OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("policy", ["householder", "gram"])
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+@pytest.mark.parametrize("m,n", [(9211, 51), (4096, 64), (100, 7), (5000, 130)])
+def test_both_r_engines(bq, oracle, torch_cuda, policy, mode, m, n):
+    """Both R-factor engines (Householder TSQR, Gram/Cholesky) give the same factorisation within tolerance in both modes."""
+    a = oracle.uniform_matrix(m, n, seed=21)
+    bq.set_policy(bq.POLICY_HOUSEHOLDER if policy == "householder" else bq.POLICY_GRAM)
+    try:
+        st, q, r = run_gpu(bq, torch_cuda, a, bq.compute_mode[mode], False)
+        eng = bq.last_engine()
+    finally:
+        bq.set_policy(bq.POLICY_AUTO)
+    assert st == 0 and eng == (0 if policy == "householder" else 1)
+    assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL
+    q2, r2 = np.linalg.qr(a.astype(np.float64))
+    qn, rn = oracle.sign_normalise(q, r)
+    q2n, r2n = oracle.sign_normalise(q2, r2)
+    assert np.abs(rn - r2n).max() / np.abs(r2n).max() < 5e-6
+    assert np.abs(qn - q2n).max() < 5e-6
+
+
+def test_auto_policy_engines_and_fallback(bq, oracle, torch_cuda):
+    """auto: fp32_tc_cor -> Gram engine, fp32_notc -> Householder; a Cholesky breakdown (cond ~1e8) falls back to Householder."""
+    a = oracle.uniform_matrix(4096, 64, seed=3)
+    run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_tc_cor, False)
+    assert bq.last_engine() == 1
+    run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_notc, False)
+    assert bq.last_engine() == 0
+    bad = oracle.matrix_with_cond(1 << 14, 64, 1e8, seed=5)
+    for reorth in (False, True):
+        st, q, r = run_gpu(bq, torch_cuda, bad, bq.compute_mode.fp32_tc_cor, reorth)
+        assert st == 0 and bq.last_engine() == 2
+        assert np.isfinite(q).all() and oracle.residual(bad, q, r) < 2e-6
+        if reorth:
+            assert oracle.orthogonality_fro(q) < 1e-5

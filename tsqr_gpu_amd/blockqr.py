@@ -42,6 +42,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_working_reorth_size", "tsqr_mi_batch_size_log2", "tsqr_mi_batch_size",
     "tsqr_mi_qr_f32", "tsqr_mi_local_r_f32", "tsqr_mi_apply_rinv_f32", "tsqr_mi_rmul_f32",
     "tsqr_mi_qr_f32_dist", "tsqr_mi_set_tuning", "tsqr_mi_profile_enable", "tsqr_mi_profile_read",
+    "tsqr_mi_set_policy", "tsqr_mi_last_engine",
 ]
 
 _lib = None
@@ -79,6 +80,9 @@ def lib():
     L.tsqr_mi_profile_enable.argtypes = [ci]
     L.tsqr_mi_profile_read.restype = ci
     L.tsqr_mi_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ci]
+    L.tsqr_mi_set_policy.restype = None
+    L.tsqr_mi_set_policy.argtypes = [ci]
+    L.tsqr_mi_last_engine.restype = ci
     L.tsqr_mi_set_tuning.restype = None
     L.tsqr_mi_set_tuning.argtypes = [ci, ci]
     _lib = L
@@ -176,7 +180,7 @@ def set_tuning(level0_waves=0, tree_chunks_per_wave=0):
     lib().tsqr_mi_set_tuning(level0_waves, tree_chunks_per_wave)
 
 
-KERNEL_CLASSES = ["fold_level0", "fold_tree", "trinv", "apply", "coupling", "other"]
+KERNEL_CLASSES = ["fold_level0", "fold_tree", "trinv", "apply", "coupling", "other", "gram", "chol"]
 
 
 def profile_enable(on=True):
@@ -185,7 +189,20 @@ def profile_enable(on=True):
 
 def profile_read():
     """{class: (milliseconds, launches)} accumulated since profile_enable(True)."""
-    ms = (ctypes.c_double * 6)()
-    cnt = (ctypes.c_long * 6)()
-    k = lib().tsqr_mi_profile_read(ms, cnt, 6)
+    ms = (ctypes.c_double * 8)()
+    cnt = (ctypes.c_long * 8)()
+    k = lib().tsqr_mi_profile_read(ms, cnt, 8)
     return {KERNEL_CLASSES[i]: (ms[i], cnt[i]) for i in range(k)}
+
+
+POLICY_AUTO, POLICY_HOUSEHOLDER, POLICY_GRAM = 0, 1, 2
+ENGINE_NAMES = {0: "householder_tsqr", 1: "gram_cholesky", 2: "gram_breakdown_then_householder"}
+
+
+def set_policy(policy):
+    """R-factor engine policy (include/tsqr_mi.h): POLICY_AUTO / POLICY_HOUSEHOLDER / POLICY_GRAM."""
+    lib().tsqr_mi_set_policy(int(policy))
+
+
+def last_engine():
+    return lib().tsqr_mi_last_engine()

@@ -86,8 +86,14 @@ __device__ __forceinline__ void load_chunk(float (&p)[NT][16], const float* __re
 // ---------------------------------------------------------------------------------------------
 // fold_kernel: streaming TPQRT.  Every wave folds `cpw` consecutive 64-row chunks of src into one
 // upper-triangular R (NP x NP, kept packed in LDS):   R <- R-factor of [R ; chunk]
-// using unblocked Householder reflectors whose top part is e_k (so R stays triangular and only
-// row k of R changes in step k).  All arithmetic fp32 FMA (used by both compute modes).
+// with Householder reflectors whose top part is e_k (R stays triangular; only row k of R changes in
+// step k).  Blocked: the 16 columns of the active tile are factored on the VALU (pivot broadcast fused
+// into the FMAs by DPP row_newbcast, 4-lane sums by v_permlane swaps); the other tiles receive the
+// block reflector I - V T^T V^T through v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains), with every
+// operand taken from registers in the (c,q) layout -- the 16x16 transposes V needs are MFMAs against
+// identity slices.  The register tiles rotate after each panel so the same 16-step code serves all of
+// them (keeps the kernel inside the instruction cache).  All arithmetic is fp32; both compute modes
+// use this kernel (the mode only selects the MFMA engine of apply_kernel).
 // ---------------------------------------------------------------------------------------------
 struct FoldArgs {
 	const float* src; size_t ld; size_t m; int n;     // source matrix (m x n, column-major)
@@ -95,64 +101,169 @@ struct FoldArgs {
 	float* dst; size_t dst_ld; int rows_store; int cols_store;   // wave w writes rows [w*rows_store, ...) of dst
 };
 
-template <int NT, int K>
-__device__ __forceinline__ void hh_step(float (&p)[NT][16], float* __restrict__ Rw, int c, int q, int n) {
-	constexpr int S = K >> 4, KK = K & 15, NP = 16 * NT;
-	constexpr int OFF = K * NP - (K * (K - 1)) / 2;      // packed row K: entry (K, col) at OFF + col - K
-	if (K >= n) return;                                  // wave-uniform
-	float x[16];
-#pragma unroll
-	for (int r = 0; r < 16; r++) x[r] = bcast16<KK>(p[S][r]);
-	float d[NT];
-#pragma unroll
-	for (int ct = S; ct < NT; ct++) {
-		float acc = 0.0f;
-#pragma unroll
-		for (int r = 0; r < 16; r++) acc = fmaf(x[r], p[ct][r], acc);
-		d[ct] = xq_sum(acc);
-	}
-	const float ss = bcast16<KK>(d[S]);                  // ||x||^2 of the pivot column (chunk part)
-	const float rkk = Rw[OFF];
-	const float nrm = sqrtf(fmaf(rkk, rkk, ss));
+// acc += (lane 16q+K of src) * other     -- one v_fmac_f32_dpp.  FIRST=true pads the two wait states a
+// VALU-written DPP source needs (hipcc does not look inside asm).
+template <int K, bool FIRST>
+__device__ __forceinline__ void fmac_bcast(float& acc, float src, float other) {
+	if constexpr (FIRST)
+		asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+		             : "+v"(acc) : "v"(src), "v"(other), "n"(K));
+	else
+		asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+		             : "+v"(acc) : "v"(src), "v"(other), "n"(K));
+}
+
+__device__ __forceinline__ float fast_rcp(float a) {     // v_rcp_f32 + one Newton step (~0.5 ulp)
+	const float r = __builtin_amdgcn_rcpf(a);
+	return fmaf(r, fmaf(-a, r, 1.0f), r);
+}
+
+// One Householder step on the active tile.  KK: column inside the tile (compile time, DPP control).
+//   p0   : the tile, 16 rows per lane (column c = lane&15)        Trow: row c of the panel's T (upper triangular)
+//   sc   : scale of this lane's own column (v_c = p0 * sc once column c has been factored)
+//   Rrow : packed row K of R in LDS, entry (K, first column of the tile + c) at Rrow[c - KK]
+//   rkk, rkc : Rrow[0] and Rrow[c - KK], loaded one step ahead by the caller (hides the LDS latency)
+// The reflector is kept orthogonal to rounding whatever the accuracy of v_sqrt/v_rcp: beta only fixes v = [1; x*inv],
+// tau is then computed from that v (tau = 2 / (1 + inv^2 ||x||^2)) and the pivot entry is updated like any other
+// column (r_kk - tau*w_k), so an inexact beta shows up as a tiny backward error, never as loss of orthogonality.
+template <int KK>
+__device__ __forceinline__ void panel_step(float (&p0)[16], float (&Trow)[16], float& sc, float* __restrict__ Rrow, int c,
+                                           float rkk, float rkc) {
+	float acc = 0.0f;
+	static_for<0, 16>([&](auto r) { fmac_bcast<KK, decltype(r)::value == 0>(acc, p0[decltype(r)::value], p0[decltype(r)::value]); });
+	const float d = xq_sum(acc);                         // x_k^T x_c for every column c of the tile
+	const float ss = bcast16<KK>(d);                     // ||x_k||^2
+	const float nrm = __builtin_amdgcn_sqrtf(fmaf(rkk, rkk, ss));
 	const bool nz = nrm > 0.0f;
 	const float beta = (rkk >= 0.0f) ? -nrm : nrm;       // -sign(rkk)*||.||, sign(0) = +1
-	const float inv = nz ? 1.0f / (rkk - beta) : 0.0f;   // v = x * inv (top entry of v is 1)
-	const float rb = nz ? 1.0f / beta : 0.0f;
-	const float tau = nz ? (beta - rkk) * rb : 0.0f;
+	const float inv = nz ? fast_rcp(rkk - beta) : 0.0f;  // v_k = x_k * inv (top entry of v is 1)
+	const float tau = nz ? 2.0f * fast_rcp(fmaf(inv * inv, ss, 1.0f)) : 0.0f;
+	const float w = fmaf(inv, d, rkc);                   // w_c = r_kc + v_k^T b_c   (c == KK: r_kk + inv*||x||^2)
+	const float tw = tau * w;
+	const bool act = c > KK;
+	const float g = act ? -tw * inv : 0.0f;              // b_c -= tau*w*v_k  ==  b_c += x_k * g
+	if (c >= KK) Rrow[c - KK] = rkc - tw;                // predicated: lanes c < KK hold a stale prefetch of a finished entry
+	static_for<0, 16>([&](auto r) { fmac_bcast<KK, false>(p0[decltype(r)::value], p0[decltype(r)::value], g); });
+	// T(0:KK, KK) = -tau * T(0:KK, 0:KK) * (V(:, 0:KK)^T v_k);   lane c owns row c of T
+	if constexpr (KK > 0) {
+		const float z = (c < KK) ? d * sc * inv : 0.0f;
+		float t = 0.0f;
+		static_for<0, KK>([&](auto l) { fmac_bcast<decltype(l)::value, decltype(l)::value == 0>(t, z, Trow[decltype(l)::value]); });
+		Trow[KK] = (c < KK) ? -tau * t : ((c == KK) ? tau : 0.0f);
+	} else {
+		Trow[0] = (c == 0) ? tau : 0.0f;
+	}
+	sc = (c == KK) ? inv : sc;
+}
+
+// block reflector of the finished panel applied to one trailing tile (all operands in registers / LDS rows of R)
+//   pj: trailing tile;  v: V of the panel in (c,q) layout (scaled);  vt[rt]: -V^T pieces (lane <-> row in tile rt)
+//   ta[r] = T[4q+r][c];  Rp: packed R in LDS;  K0: first column of the panel;  colj: first column of the trailing tile
+__device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[16], const f32x4 (&vt)[4], const float (&ta)[4],
+                                             float* __restrict__ Rp, int K0, int colj, int NP, int c, int q) {
+	// W0 = rows K0..K0+15 of R restricted to this tile, D layout (row 4q+r, column c)
+	int idx[4];
+	f32x4 w0;
 #pragma unroll
-	for (int ct = S; ct < NT; ct++) {
-		const int col = 16 * ct + c;
-		const float rkc = Rw[OFF + col - K];             // lanes with col < K read a harmless neighbour
-		const float w = fmaf(inv, d[ct], rkc);           // w = r_kc + v^T b_c
-		const bool act = col > K;
-		const float g = act ? w * rb : 0.0f;             // b_c -= tau*w*v  ==  b_c += x * (w/beta)
-		if (q == 0) {
-			if (act) Rw[OFF + col - K] = fmaf(-tau, w, rkc);
-			else if (col == K) Rw[OFF] = nz ? beta : rkk;
-		}
+	for (int r = 0; r < 4; r++) {
+		const int k = K0 + 4 * q + r;
+		idx[r] = k * NP - (k * (k - 1)) / 2 + (colj + c - k);
+		w0[r] = Rp[idx[r]];
+	}
+	f32x4 w = w0;                                        // W = W0 + V^T B
 #pragma unroll
-		for (int r = 0; r < 16; r++) p[ct][r] = fmaf(x[r], g, p[ct][r]);
+	for (int rho = 0; rho < 16; rho++) w = __builtin_amdgcn_mfma_f32_16x16x4f32(v[rho], pj[rho], w, 0, 0, 0);
+	f32x4 wp = {0.f, 0.f, 0.f, 0.f};                     // W' = T^T W   (k-slot (q, r) <-> panel column 4q+r)
+#pragma unroll
+	for (int r = 0; r < 4; r++) wp = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[r], w[r], wp, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 4; r++) Rp[idx[r]] = w0[r] - wp[r];
+#pragma unroll
+	for (int rt = 0; rt < 4; rt++) {                     // B -= V W'
+		f32x4 acc = {pj[4 * rt], pj[4 * rt + 1], pj[4 * rt + 2], pj[4 * rt + 3]};
+#pragma unroll
+		for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[rt][r], wp[r], acc, 0, 0, 0);
+		pj[4 * rt] = acc[0]; pj[4 * rt + 1] = acc[1]; pj[4 * rt + 2] = acc[2]; pj[4 * rt + 3] = acc[3];
 	}
 }
 
+#ifndef TSQR_FOLD_WAVES_PER_SIMD
+#define TSQR_FOLD_WAVES_PER_SIMD 2
+#endif
 template <int NT>
-__global__ __launch_bounds__(256) void fold_kernel(const FoldArgs a) {
+__global__ __launch_bounds__(256, TSQR_FOLD_WAVES_PER_SIMD) void fold_kernel(const FoldArgs a) {
 	constexpr int NP = 16 * NT;
 	constexpr int RP = (NP * (NP + 1)) / 2 + 16;         // packed upper triangle (+ slack for masked reads)
 	__shared__ float Rs[4][RP];
+	__shared__ float Ts[4][256];
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	const int gw = blockIdx.x * 4 + wv;
 	if (gw >= a.nwaves) return;                          // whole waves leave; no barrier in this kernel
 	const int c = lane & 15, q = lane >> 4;
 	float* Rw = Rs[wv];
+	float* Tl = Ts[wv];
 	for (int i = lane; i < RP; i += 64) Rw[i] = 0.0f;
+	const int ntile = (a.n + 15) >> 4;                   // tiles that carry data
 
 	float p[NT][16];
 	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
 	for (int ch = gw * a.cpw; ch < ch_end; ch++) {
 		load_chunk<NT>(p, a.src, a.ld, (size_t)ch * 64, a.m, a.n, c, q);
-		static_for<0, NP>([&](auto kc) { hh_step<NT, decltype(kc)::value>(p, Rw, c, q, a.n); });
+#pragma unroll 1
+		for (int S = 0; S < ntile; S++) {
+			const int K0 = 16 * S;
+			float Trow[16];
+#pragma unroll
+			for (int l = 0; l < 16; l++) Trow[l] = 0.0f;
+			float sc = 1.0f;
+			int offK = K0 * NP - (K0 * (K0 - 1)) / 2;    // packed offset of entry (K0, K0)
+			float rkk = Rw[offK], rkc = Rw[offK + c];    // row K0, prefetched
+			static_for<0, 16>([&](auto kk) {
+				constexpr int KK = decltype(kk)::value;
+				const int offN = offK + NP - (K0 + KK);  // row K+1
+				float rkk_n = 0.0f, rkc_n = 0.0f;
+				if (KK < 15) { rkk_n = Rw[offN]; rkc_n = Rw[offN + c - (KK + 1)]; }   // not touched by step KK
+				if (K0 + KK < a.n) panel_step<KK>(p[0], Trow, sc, Rw + offK, c, rkk, rkc);
+				offK = offN; rkk = rkk_n; rkc = rkc_n;
+			});
+			const int ntrail = ntile - 1 - S;
+			if (ntrail > 0) {
+#pragma unroll
+				for (int r = 0; r < 16; r++) p[0][r] *= sc;              // V of the panel
+				if (q == 0) {
+#pragma unroll
+					for (int l = 0; l < 16; l += 4) {
+						f32x4 tv = {Trow[l], Trow[l + 1], Trow[l + 2], Trow[l + 3]};
+						*reinterpret_cast<f32x4*>(&Tl[c * 16 + l]) = tv;
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+				float ta[4];
+#pragma unroll
+				for (int r = 0; r < 4; r++) ta[r] = Tl[(4 * q + r) * 16 + c];
+				f32x4 vt[4];                                  // -V^T per 16-row tile via MFMA against identity slices
+#pragma unroll
+				for (int rt = 0; rt < 4; rt++) {
+					f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+					for (int r = 0; r < 4; r++)
+						t = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][4 * rt + r], (c == 4 * q + r) ? -1.0f : 0.0f, t, 0, 0, 0);
+					vt[rt] = t;
+				}
+				static_for<1, NT>([&](auto jj) {
+					constexpr int J = decltype(jj)::value;
+					if (J <= ntrail) trail_update(p[J], p[0], vt, ta, Rw, K0, K0 + 16 * J, NP, c, q);
+				});
+				__builtin_amdgcn_wave_barrier();
+			}
+			// rotate the tiles: the next panel becomes p[0]
+			static_for<0, NT - 1>([&](auto jj) {
+				constexpr int J = decltype(jj)::value;
+#pragma unroll
+				for (int r = 0; r < 16; r++) p[J][r] = p[J + 1][r];
+			});
+		}
 	}
 	// write R: lane <-> row, loop over columns (consecutive lanes -> consecutive addresses)
 	float* dst = a.dst + (size_t)gw * a.rows_store;
@@ -162,6 +273,195 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldArgs a) {
 			const float v = (lane <= col && lane < NP && col < NP) ? Rw[off + col - lane] : 0.0f;
 			dst[(size_t)col * a.dst_ld + lane] = v;
 		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram engine (R-factor engine of fp32_tc_cor):  G = A^T A on the fp64 matrix cores, R = chol(G) in fp64.
+// Products of fp32 inputs are exact in fp64 and the accumulation is fp64, so R is as backward-accurate as an fp32
+// Householder R while cond(A)^2 * 2^-53 * n << 1; chol_kernel reports breakdown and the host falls back to fold_kernel.
+//   gram_kernel        : every wave accumulates the upper-triangular 16x16 tiles of its strip's Gram matrix with
+//                        v_mfma_f64_16x16x4_f64 (both operands straight from the (c,q) registers), the four waves of a
+//                        workgroup are summed through LDS, one partial per workgroup goes to HBM.
+//   gram_reduce_kernel : partials -> NSPLIT sub-sums per entry (fixed order: deterministic).
+//   chol_kernel        : sub-sums -> G (LDS, fp64) -> R (fp32, user layout), Z = inverse(R) (fp32, NP x NP), status.
+// ---------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct GramArgs {
+	const float* a; size_t lda; size_t m; int n;
+	int nchunks; int cpw; int nwaves;
+	double* part;                        // [gridDim.x][NTRI][256]  (tile, lane, reg) order of the MFMA accumulators
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
+	constexpr int NTRI = (NT * (NT + 1)) / 2;
+	__shared__ double red[2][NTRI * 256];
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int gw = blockIdx.x * 4 + wv;
+	const int c = lane & 15, q = lane >> 4;
+	f64x4 acc[NTRI];
+#pragma unroll
+	for (int t = 0; t < NTRI; t++) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+	if (gw < a.nwaves) {
+		float p[NT][16];
+		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
+		for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+			load_chunk<NT>(p, a.a, a.lda, (size_t)ch * 64, a.m, a.n, c, q);
+#pragma unroll
+			for (int rho = 0; rho < 16; rho++) {
+				double pd[NT];
+#pragma unroll
+				for (int t = 0; t < NT; t++) pd[t] = (double)p[t][rho];
+				int idx = 0;
+#pragma unroll
+				for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+					for (int tj = ti; tj < NT; tj++) {
+						acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(pd[ti], pd[tj], acc[idx], 0, 0, 0);
+						idx++;
+					}
+			}
+		}
+	}
+	// workgroup sum: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the partial
+	if (wv >= 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[wv - 2][(t * 4 + r) * 64 + lane] = acc[t][r];
+	}
+	__syncthreads();
+	if (wv < 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) acc[t][r] += red[wv][(t * 4 + r) * 64 + lane];
+	}
+	__syncthreads();
+	if (wv == 1) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[0][(t * 4 + r) * 64 + lane] = acc[t][r];
+	}
+	__syncthreads();
+	if (wv == 0) {
+		double* out = a.part + (size_t)blockIdx.x * NTRI * 256;
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = acc[t][r] + red[0][(t * 4 + r) * 64 + lane];
+	}
+}
+
+// sub[s][e] = sum of part[b][e] over b = s, s+NSPLIT, ...   (e < nelem)
+__global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ sub, const double* __restrict__ part,
+                                                          int nblocks, int nelem, int nsplit) {
+	const int e = blockIdx.x * 256 + threadIdx.x;
+	const int sidx = blockIdx.y;
+	if (e >= nelem) return;
+	double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+	int b = sidx;
+	for (; b + 3 * nsplit < nblocks; b += 4 * nsplit) {
+		s0 += part[(size_t)b * nelem + e];
+		s1 += part[(size_t)(b + nsplit) * nelem + e];
+		s2 += part[(size_t)(b + 2 * nsplit) * nelem + e];
+		s3 += part[(size_t)(b + 3 * nsplit) * nelem + e];
+	}
+	for (; b < nblocks; b += nsplit) s0 += part[(size_t)b * nelem + e];
+	sub[(size_t)sidx * nelem + e] = (s0 + s1) + (s2 + s3);
+}
+
+// status[0]: 0 ok, 1 breakdown (a pivot fell below 2^-40 of its diagonal entry: cond(A)^2 is beyond fp64 Cholesky)
+// status[1]: bit pattern of the smallest pivot ratio (float) for diagnostics
+__global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
+                                                   const double* __restrict__ sub, int nsplit, int n, int NT) {
+	__shared__ double Gs[64 * 65];               // symmetric G, then R in the upper triangle: Gs[row * 65 + col]
+	__shared__ double Zs[64 * 65];               // Z = inverse(R): Zs[col * 65 + row]
+	__shared__ double dg[64];
+	__shared__ float minratio[4];
+	const int t = threadIdx.x;
+	const int NP = 16 * NT;
+	const int ntri = (NT * (NT + 1)) / 2;
+	const int nelem = ntri * 256;
+	for (int i = t; i < 64 * 65; i += 256) { Gs[i] = 0.0; Zs[i] = 0.0; }
+	__syncthreads();
+	{
+		int idx = 0;
+		for (int ti = 0; ti < NT; ti++)
+			for (int tj = ti; tj < NT; tj++, idx++)
+				for (int e = t; e < 256; e += 256) {
+					const int reg = e >> 6, l = e & 63;
+					double v = 0.0;
+					for (int sidx = 0; sidx < nsplit; sidx++) v += sub[(size_t)sidx * nelem + idx * 256 + e];
+					const int row = 16 * ti + (l >> 4) + 4 * reg;      // f64 MFMA C/D layout: row = (lane>>4) + 4*reg, col = lane&15
+					const int col = 16 * tj + (l & 15);
+					Gs[row * 65 + col] = v;
+					Gs[col * 65 + row] = v;
+				}
+	}
+	__syncthreads();
+	if (t < 64) dg[t] = Gs[t * 65 + t];
+	float worst = 1.0f;
+	__syncthreads();
+	// right-looking Cholesky, G = R^T R; thread owns column j = t & 63 and rows i = (t >> 6) + 4 s
+	const int j = t & 63, ib = t >> 6;
+	for (int k = 0; k < n; k++) {
+		double piv = Gs[k * 65 + k];
+		const double d0 = dg[k];
+		const float ratio = (d0 > 0.0) ? (float)(piv / d0) : 0.0f;
+		worst = fminf(worst, ratio);
+		if (!(piv > d0 * 9.094947017729282e-13)) piv = (d0 > 0.0 ? d0 : 1.0) * 9.094947017729282e-13;   // 2^-40: keep going, flagged
+		const double rkk = sqrt(piv);
+		const double rinv = 1.0 / rkk;
+		__syncthreads();
+		if (t == 0) Gs[k * 65 + k] = rkk;
+		if (t > k && t < n) Gs[k * 65 + t] *= rinv;         // row k of R
+		__syncthreads();
+		if (j > k && j < n) {
+			const double rkj = Gs[k * 65 + j];
+#pragma unroll 4
+			for (int s = 0; s < 16; s++) {
+				const int i = ib + 4 * s;
+				if (i > k && i <= j) Gs[i * 65 + j] -= Gs[k * 65 + i] * rkj;
+			}
+		}
+		__syncthreads();
+	}
+	// breakdown flag
+	for (int o = 32; o > 0; o >>= 1) worst = fminf(worst, __shfl_xor(worst, o));
+	if ((t & 63) == 0) minratio[t >> 6] = worst;
+	__syncthreads();
+	if (t == 0) {
+		const float w = fminf(fminf(minratio[0], minratio[1]), fminf(minratio[2], minratio[3]));
+		status[0] = (w > 9.094947017729282e-13f) ? 0u : 1u;
+		status[1] = __builtin_bit_cast(unsigned, w);
+	}
+	// R out (fp32, exact zeros below the diagonal)
+	for (int e = t; e < n * n; e += 256) {
+		const int i = e % n, jj = e / n;
+		r[(size_t)jj * ldr + i] = (i <= jj) ? (float)Gs[i * 65 + jj] : 0.0f;
+	}
+	// Z = inverse(R): 4 threads per column (jz = t >> 2, part s = t & 3), back substitution from the diagonal upwards
+	{
+		const int jz = t >> 2, sp = t & 3;
+		for (int i = n - 1; i >= 0; i--) {
+			double partial = 0.0;
+			if (jz < n && i < jz)
+				for (int k = i + 1 + sp; k <= jz; k += 4) partial += Gs[i * 65 + k] * Zs[jz * 65 + k];
+			partial += __shfl_xor(partial, 1);
+			partial += __shfl_xor(partial, 2);
+			if (sp == 0 && jz < n && i <= jz) Zs[jz * 65 + i] = ((i == jz ? 1.0 : 0.0) - partial) / Gs[i * 65 + i];
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	__syncthreads();
+	for (int e = t; e < NP * NP; e += 256) {
+		const int i = e % NP, jj = e / NP;
+		z[(size_t)jj * NP + i] = (i <= jj && jj < n) ? (float)Zs[jj * 65 + i] : 0.0f;
 	}
 }
 

@@ -27,9 +27,13 @@ namespace {
 thread_local std::string g_last_error;
 int g_level0_waves = 2048;
 int g_tree_cpw = 4;
+int g_policy = 0;        // 0 auto (fp32_tc_cor: Gram engine with Householder fallback; fp32_notc: Householder), 1 Householder, 2 Gram
+int g_last_engine = 0;   // 0 Householder TSQR, 1 Gram/Cholesky, 2 Gram broke down -> Householder fallback
+constexpr int GRAM_NSPLIT = 16;
+constexpr int GRAM_WAVES = 2048;
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
-enum { KC_FOLD0 = 0, KC_TREE = 1, KC_TRINV = 2, KC_APPLY = 3, KC_COUPLE = 4, KC_MISC = 5, KC_COUNT = 6 };
+enum { KC_FOLD0 = 0, KC_TREE = 1, KC_TRINV = 2, KC_APPLY = 3, KC_COUPLE = 4, KC_MISC = 5, KC_GRAM = 6, KC_CHOL = 7, KC_COUNT = 8 };
 struct Prof {
 	bool on = false;
 	static constexpr int MAXEV = 4096;
@@ -37,8 +41,8 @@ struct Prof {
 	int cls[MAXEV];
 	int n = 0;
 	bool created = false;
-	double ms[KC_COUNT] = {0, 0, 0, 0, 0, 0};
-	long launches[KC_COUNT] = {0, 0, 0, 0, 0, 0};
+	double ms[KC_COUNT] = {};
+	long launches[KC_COUNT] = {};
 } g_prof;
 struct ProfScope {                 // brackets one kernel launch (or a short launch group) with two events
 	int idx = -1; hipStream_t st;
@@ -118,8 +122,22 @@ Plan make_plan(size_t m, size_t n) {
 	return p;
 }
 
-// layout of wq (floats): [stack_b][Z: 4096][S: 4096][part: NSLAB*4096][R1 copy: n*n][R2: n*n]
-struct WqLayout { size_t z, s, part, r1, r2, total; };
+// Gram engine geometry: waves / workgroups of gram_kernel and the size of its per-workgroup partials (in floats)
+struct GramPlan { int nch, cpw, nwaves, nblocks, ntri; size_t part_floats; };
+GramPlan gram_plan(size_t m, size_t n) {
+	GramPlan g{};
+	const size_t NT = np_of(n) / 16;
+	g.nch = (int)cdiv(m, 64);
+	g.cpw = (int)std::max<size_t>(1, cdiv((size_t)g.nch, (size_t)GRAM_WAVES));
+	g.nwaves = (int)cdiv((size_t)g.nch, (size_t)g.cpw);
+	g.nblocks = (g.nwaves + 3) / 4;
+	g.ntri = (int)(NT * (NT + 1) / 2);
+	g.part_floats = (size_t)g.nblocks * g.ntri * 256 * 2;
+	return g;
+}
+
+// layout of wq (floats): [stack_b][Z: 4096][S: 4096][part: NSLAB*4096][R1 copy: n*n][R2: n*n][gram sub-sums][status]
+struct WqLayout { size_t z, s, part, r1, r2, gsub, status, total; };
 WqLayout wq_layout(size_t m, size_t n) {
 	const Plan p = make_plan(m, n);
 	WqLayout L{};
@@ -130,6 +148,9 @@ WqLayout wq_layout(size_t m, size_t n) {
 	L.part = o; o += (n > PW ? (size_t)NSLAB * 4096 : 0);
 	L.r1 = o; o += n * n;
 	L.r2 = o; o += n * n;
+	o = (o + 63) & ~(size_t)63;
+	L.gsub = o; o += (size_t)GRAM_NSPLIT * 10 * 256 * 2;
+	L.status = o; o += 64;
 	L.total = o;
 	return L;
 }
@@ -175,6 +196,42 @@ int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n
 	return 0;
 }
 
+template <int NT> void launch_gram(const tsqrmi::GramArgs& a, int nblocks, hipStream_t st) {
+	hipLaunchKernelGGL(tsqrmi::gram_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
+}
+
+// Gram engine: R (n x n, ldr) and Z = inverse(R) (NP x NP in z_buf) of src (m x n); status -> wq[L.status]
+int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size_t m, size_t n,
+           float* wq, float* wr, const WqLayout& L, hipStream_t st) {
+	const GramPlan g = gram_plan(m, n);
+	const int NT = (int)(np_of(n) / 16);
+	tsqrmi::GramArgs a{};
+	a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
+	a.part = reinterpret_cast<double*>(wr);
+	{
+		ProfScope ps(KC_GRAM, st);
+		switch (NT) {
+			case 1: launch_gram<1>(a, g.nblocks, st); break;
+			case 2: launch_gram<2>(a, g.nblocks, st); break;
+			case 3: launch_gram<3>(a, g.nblocks, st); break;
+			default: launch_gram<4>(a, g.nblocks, st); break;
+		}
+	}
+	HIPCHK(hipGetLastError());
+	const int nelem = g.ntri * 256;
+	const int nsplit = std::min(GRAM_NSPLIT, g.nblocks);
+	double* sub = reinterpret_cast<double*>(wq + L.gsub);
+	{
+		ProfScope ps(KC_CHOL, st);
+		hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
+		                   sub, a.part, g.nblocks, nelem, nsplit);
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
+		                   reinterpret_cast<unsigned*>(wq + L.status), sub, nsplit, (int)n, NT);
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 template <int E, int NT> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
 	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
 	const size_t lds = sizeof(float) * 4 * NP * 68 + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)3 * KT * NT * 512 * 2);
@@ -199,10 +256,10 @@ template <int E> int dispatch_apply_nt(int NT, const tsqrmi::ApplyArgs& a, hipSt
 
 // q = a * inverse(r); n <= 64; z_buf: 4096 floats of scratch
 int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, const float* r, size_t ldr,
-               size_t m, size_t n, float* z_buf, hipStream_t st) {
+               size_t m, size_t n, float* z_buf, hipStream_t st, bool z_ready = false) {
 	const size_t NP = np_of(n);
 	const int NT = (int)(NP / 16);
-	{
+	if (!z_ready) {
 		ProfScope ps(KC_TRINV, st);
 		hipLaunchKernelGGL(tsqrmi::trinv_kernel, dim3(1), dim3(64), 0, st, z_buf, r, ldr, (int)n, (int)NP);
 	}
@@ -230,9 +287,48 @@ int engine_of(int mode) {
 	return -1;
 }
 
+// read the Gram engine's status word (0 ok / 1 breakdown) after draining the stream
+int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStream_t st, unsigned* out) {
+	if (h_pinned) {
+		HIPCHK(hipMemcpyAsync(h_pinned, wq + L.status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		*out = h_pinned[0];
+	} else {
+		HIPCHK(hipStreamSynchronize(st));
+		HIPCHK(hipMemcpy(out, wq + L.status, sizeof(unsigned), hipMemcpyDeviceToHost));
+	}
+	return 0;
+}
+
+// R factor (and Q) of one <= 64-column panel.  use_gram: Gram/Cholesky engine, otherwise the Householder TSQR engine.
+// check_now: verify the Gram engine's status immediately (one stream sync) and fall back to Householder on breakdown.
+int panel_qr(int engine, bool use_gram, bool check_now, float* qp, size_t ldq, float* rpp, size_t ldr, const float* ap, size_t lda,
+             size_t m, size_t c, float* wq, float* wr, const WqLayout& L, unsigned* h_pinned, hipStream_t st) {
+	int rc;
+	if (use_gram) {
+		rc = gram_r(rpp, ldr, wq + L.z, ap, lda, m, c, wq, wr, L, st);
+		if (rc) return rc;
+		bool ok = true;
+		if (check_now) {
+			unsigned status = 0;
+			rc = read_status(wq, L, h_pinned, st, &status);
+			if (rc) return rc;
+			ok = (status == 0);
+		}
+		if (ok) {
+			g_last_engine = std::max(g_last_engine, 1);
+			return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st, /*z_ready=*/true);
+		}
+		g_last_engine = 2;
+	}
+	rc = fold_r(rpp, ldr, ap, lda, m, c, wq, wr, st);
+	if (rc) return rc;
+	return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st);
+}
+
 // one sweep of 64-wide-panel block QR:  (q, r) <- qr(a);  a is overwritten for n > 64; q may alias a.
-int sweep(int engine, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n,
-          float* wq, float* wr, const WqLayout& L, hipStream_t st) {
+int sweep(int engine, bool use_gram, bool check_now, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n,
+          float* wq, float* wr, const WqLayout& L, unsigned* h_pinned, hipStream_t st) {
 	const size_t npanels = cdiv(n, PW);
 	for (size_t pi = 0; pi < npanels; pi++) {
 		const size_t P = pi * PW, c = std::min(PW, n - P);
@@ -250,10 +346,7 @@ int sweep(int engine, float* q, size_t ldq, float* r, size_t ldr, float* a, size
 			                   ap, lda, q + B * ldq, ldq, wq + L.s, m, (int)PW, (int)c);
 			HIPCHK(hipGetLastError());
 		}
-		float* rpp = r + P * ldr + P;
-		int rc = fold_r(rpp, ldr, ap, lda, m, c, wq, wr, st);
-		if (rc) return rc;
-		rc = apply_rinv(engine, q + P * ldq, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st);
+		const int rc = panel_qr(engine, use_gram, check_now, q + P * ldq, ldq, r + P * ldr + P, ldr, ap, lda, m, c, wq, wr, L, h_pinned, st);
 		if (rc) return rc;
 	}
 	return 0;
@@ -276,7 +369,10 @@ size_t tsqr_mi_working_q_size(size_t m, size_t n) {
 size_t tsqr_mi_working_r_size(size_t m, size_t n) {
 	if (m == 0 || n == 0) return 0;
 	size_t need = 0;
-	for (size_t P = 0; P < n; P += PW) need = std::max(need, make_plan(m, std::min(PW, n - P)).stack_a);
+	for (size_t P = 0; P < n; P += PW) {
+		need = std::max(need, make_plan(m, std::min(PW, n - P)).stack_a);
+		need = std::max(need, gram_plan(m, std::min(PW, n - P)).part_floats);
+	}
 	// the stack of a dist/gathered fold is tiny; nothing extra needed
 	return std::max(ref_wr(m, n), need);
 }
@@ -299,6 +395,9 @@ int tsqr_mi_profile_read(double* ms, long* launches, int max_classes) {
 	return k;
 }
 
+void tsqr_mi_set_policy(int policy) { if (policy >= 0 && policy <= 2) g_policy = policy; }
+int tsqr_mi_last_engine(void) { return g_last_engine; }
+
 void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave) {
 	if (level0_waves > 0) g_level0_waves = level0_waves;
 	if (tree_chunks_per_wave > 1) g_tree_cpw = tree_chunks_per_wave;
@@ -307,7 +406,7 @@ void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave) {
 int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                    size_t m, size_t n, void* wq_v, void* wr_v, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
                    void* stream) {
-	(void)reorth_w; (void)d_wl; (void)h_wl;
+	(void)reorth_w; (void)d_wl;
 	if (n > m || m == 0 || n == 0) return TSQR_MI_ERROR_INVALID_SIZE;     // reference src/blockqr.cu:409-411
 	const int engine = engine_of(mode);
 	if (engine < 0) { g_last_error = "compute_mode not implemented on gfx950"; return TSQR_MI_ERROR_UNSUPPORTED; }
@@ -315,22 +414,40 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	float* wq = reinterpret_cast<float*>(wq_v);
 	float* wr = reinterpret_cast<float*>(wr_v);
 	const WqLayout L = wq_layout(m, n);
-
-	int rc = sweep(engine, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, st);
-	if (rc) return rc;
+	const bool use_gram = (g_policy == 2) || (g_policy == 0 && mode == TSQR_MI_FP32_TC_COR);
+	const bool may_fall_back = use_gram && g_policy == 0;
+	// single panel, single sweep: run speculatively and look at the status at the final sync (A is untouched for n <= 64);
+	// otherwise (several panels or a second sweep consuming Q) verify each panel right away.
+	const bool deferred = may_fall_back && n <= PW && !reorth;
+	const bool check_now = may_fall_back && !deferred;
 	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
-	if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, st, r, ldr, (int)n);
-	if (reorth) {
-		// second sweep on Q in place: Q <- Q * inverse(R2), R <- R2 * R   (the reference's BCGS2 plays this role)
-		float* r1 = wq + L.r1; float* r2 = wq + L.r2;
-		hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(gb), dim3(256), 0, st, r1, n, r, ldr, (int)n, (int)n);
-		HIPCHK(hipMemsetAsync(r2, 0, sizeof(float) * n * n, st));
-		rc = sweep(engine, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, st);
+	g_last_engine = 0;
+
+	for (int attempt = 0; attempt < 2; attempt++) {
+		const bool gram_now = use_gram && attempt == 0;
+		int rc = sweep(engine, gram_now, check_now, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
 		if (rc) return rc;
-		hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
+		if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, st, r, ldr, (int)n);
+		if (reorth) {
+			// second sweep on Q in place: Q <- Q * inverse(R2), R <- R2 * R   (the reference's BCGS2 plays this role)
+			float* r1 = wq + L.r1; float* r2 = wq + L.r2;
+			hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(gb), dim3(256), 0, st, r1, n, r, ldr, (int)n, (int)n);
+			HIPCHK(hipMemsetAsync(r2, 0, sizeof(float) * n * n, st));
+			rc = sweep(engine, gram_now, check_now, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
+			if (rc) return rc;
+			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
+		}
+		HIPCHK(hipGetLastError());
+		if (gram_now && deferred) {
+			unsigned status = 0;
+			rc = read_status(wq, L, h_wl, st, &status);
+			if (rc) return rc;
+			if (status != 0) { g_last_engine = 2; continue; }     // breakdown: redo with the Householder engine
+		} else {
+			HIPCHK(hipStreamSynchronize(st));
+		}
+		break;
 	}
-	HIPCHK(hipGetLastError());
-	HIPCHK(hipStreamSynchronize(st));
 	prof_collect();
 	return TSQR_MI_SUCCESS;
 }
