@@ -96,11 +96,14 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth,
 void tsqr_mi_profile_enable(int on);
 int tsqr_mi_profile_read(double* ms, long* launches, int max_classes);
 
-/* R-factor engine policy.  0 (default) auto: fp32_tc_cor uses the Gram engine (G = A^T A on the fp64 matrix cores,
- * R = chol(G) in fp64) and falls back to the Householder TSQR engine when the Cholesky factorisation reports
- * breakdown (cond(A) beyond ~1e6); fp32_notc always uses Householder TSQR (fp32 arithmetic only).
- * 1: always Householder TSQR.  2: always Gram (no fallback; for tests).
- * tsqr_mi_last_engine(): engine of the last tsqr_mi_qr_f32 call: 0 Householder, 1 Gram, 2 Gram broke down -> Householder. */
+/* R-factor engine policy (Q is always formed by apply: Q = A * inverse(R) on the MFMA units).
+ *   0 auto (default): fp32_notc -> Householder TSQR (fp32 arithmetic only).
+ *                     fp32_tc_cor -> Gram engine, R = chol(A^T A):  first the bf16x3-split MFMA Gram matrix (memory-bound),
+ *                     accepted when every Cholesky pivot keeps >= 2^-5 of its diagonal entry (nearly orthogonal columns);
+ *                     else the fp64-MFMA Gram matrix, accepted down to 2^-40 (cond(A) up to ~1e6); else Householder TSQR.
+ *   1 always Householder TSQR.   2 always fp64 Gram (no fallback).   3 always bf16-split Gram (no check; tests only).
+ *   4 auto without the bf16-split level.
+ * tsqr_mi_last_engine(): 0 Householder, 1 fp64 Gram, 2 Gram rejected -> Householder, 3 bf16-split Gram. */
 void tsqr_mi_set_policy(int policy);
 int tsqr_mi_last_engine(void);
 

@@ -185,19 +185,20 @@ def test_cpp_sample_through_header(bq, torch_cuda):
     assert out.returncode == 0 and "SAMPLE OK" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("policy", ["householder", "gram"])
+@pytest.mark.parametrize("policy", ["householder", "gram_f64", "gram_bf16"])
 @pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
 @pytest.mark.parametrize("m,n", [(9211, 51), (4096, 64), (100, 7), (5000, 130)])
-def test_both_r_engines(bq, oracle, torch_cuda, policy, mode, m, n):
-    """Both R-factor engines (Householder TSQR, Gram/Cholesky) give the same factorisation within tolerance in both modes."""
+def test_all_r_engines(bq, oracle, torch_cuda, policy, mode, m, n):
+    """The three R-factor engines (Householder TSQR, fp64 Gram, bf16-split Gram) agree within tolerance in both modes."""
     a = oracle.uniform_matrix(m, n, seed=21)
-    bq.set_policy(bq.POLICY_HOUSEHOLDER if policy == "householder" else bq.POLICY_GRAM)
+    pol = {"householder": bq.POLICY_HOUSEHOLDER, "gram_f64": bq.POLICY_GRAM_F64, "gram_bf16": bq.POLICY_GRAM_BF16}[policy]
+    bq.set_policy(pol)
     try:
         st, q, r = run_gpu(bq, torch_cuda, a, bq.compute_mode[mode], False)
         eng = bq.last_engine()
     finally:
         bq.set_policy(bq.POLICY_AUTO)
-    assert st == 0 and eng == (0 if policy == "householder" else 1)
+    assert st == 0 and eng == {"householder": 0, "gram_f64": 1, "gram_bf16": 3}[policy]
     assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL
     q2, r2 = np.linalg.qr(a.astype(np.float64))
     qn, rn = oracle.sign_normalise(q, r)
@@ -206,17 +207,29 @@ def test_both_r_engines(bq, oracle, torch_cuda, policy, mode, m, n):
     assert np.abs(qn - q2n).max() < 5e-6
 
 
-def test_auto_policy_engines_and_fallback(bq, oracle, torch_cuda):
-    """auto: fp32_tc_cor -> Gram engine, fp32_notc -> Householder; a Cholesky breakdown (cond ~1e8) falls back to Householder."""
+def test_auto_policy_escalation(bq, oracle, torch_cuda):
+    """auto: fp32_notc -> Householder; fp32_tc_cor -> bf16-split Gram for nearly orthogonal columns, fp64 Gram for moderate
+    cond, Householder when the Cholesky factorisation is rejected (cond ~1e8)."""
     a = oracle.uniform_matrix(4096, 64, seed=3)
     run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_tc_cor, False)
-    assert bq.last_engine() == 1
+    assert bq.last_engine() == 3
     run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_notc, False)
     assert bq.last_engine() == 0
+    # a matrix whose Gram matrix is numerically singular in fp64 must end in the Householder engine
+    sing = oracle.uniform_matrix(8192, 64, seed=8)
+    sing[:, 63] = sing[:, 0] * 0.5 + sing[:, 1] * 0.25                # exact linear dependence (rank 63)
+    st, q, r = run_gpu(bq, torch_cuda, sing, bq.compute_mode.fp32_tc_cor, False)
+    assert st == 0 and bq.last_engine() == 2 and oracle.residual(sing, q, r) < 2e-6
+    mid = oracle.matrix_with_cond(1 << 14, 64, 1e3, seed=5)
+    for reorth in (False, True):
+        st, q, r = run_gpu(bq, torch_cuda, mid, bq.compute_mode.fp32_tc_cor, reorth)
+        assert st == 0 and bq.last_engine() in (1, 3)
+        assert oracle.residual(mid, q, r) < 2e-6
+        assert oracle.orthogonality_fro(q) < (1e-5 if reorth else 1e-2)
     bad = oracle.matrix_with_cond(1 << 14, 64, 1e8, seed=5)
     for reorth in (False, True):
         st, q, r = run_gpu(bq, torch_cuda, bad, bq.compute_mode.fp32_tc_cor, reorth)
-        assert st == 0 and bq.last_engine() == 2
+        assert st == 0 and bq.last_engine() in (1, 2)              # never the bf16-split level
         assert np.isfinite(q).all() and oracle.residual(bad, q, r) < 2e-6
         if reorth:
             assert oracle.orthogonality_fro(q) < 1e-5

@@ -1,0 +1,16 @@
+import sys, ctypes, torch
+L = ctypes.CDLL('tsqr_gpu_amd/csrc/libtsqr_selftest.so')
+L.tsqr_selftest_copy_time.restype = ctypes.c_float
+L.tsqr_selftest_copy_time.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+m, n = 1 << 20, 64
+a = torch.rand(n, m, device='cuda'); q = torch.empty(n, m, device='cuda')
+for mode in (0, 1):
+    for waves in (1024, 2048, 4096, 8192, 16384):
+        ms = L.tsqr_selftest_copy_time(q.data_ptr(), a.data_ptr(), m, mode, waves, 20)
+        print('mode %d waves %5d: %.1f us  %.2f TB/s' % (mode, waves, ms * 1e3, 2 * 4 * m * n / ms / 1e9))
+    assert torch.equal(a, q)
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+q.copy_(a); t0.record()
+for _ in range(20): q.copy_(a)
+t1.record(); torch.cuda.synchronize()
+print('torch copy_: %.1f us' % (t0.elapsed_time(t1) / 20 * 1e3))

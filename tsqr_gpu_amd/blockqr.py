@@ -57,6 +57,9 @@ def lib():
         raise RuntimeError(
             "tsqr_gpu_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C tsqr_gpu_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # torch first: its bundled HIP runtime must be the one libtsqr_mi.so binds to (loading the library before torch
+    # pulls the system libamdhip64 and the process ends up with two runtimes -- "no ROCm-capable device")
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     sz, vp, ci = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
     L.tsqr_mi_version.restype = ci
@@ -195,12 +198,12 @@ def profile_read():
     return {KERNEL_CLASSES[i]: (ms[i], cnt[i]) for i in range(k)}
 
 
-POLICY_AUTO, POLICY_HOUSEHOLDER, POLICY_GRAM = 0, 1, 2
-ENGINE_NAMES = {0: "householder_tsqr", 1: "gram_cholesky", 2: "gram_breakdown_then_householder"}
+POLICY_AUTO, POLICY_HOUSEHOLDER, POLICY_GRAM_F64, POLICY_GRAM_BF16, POLICY_AUTO_NO_BF16 = 0, 1, 2, 3, 4
+ENGINE_NAMES = {0: "householder_tsqr", 1: "gram_f64_cholesky", 2: "gram_rejected_then_householder", 3: "gram_bf16x3_cholesky"}
 
 
 def set_policy(policy):
-    """R-factor engine policy (include/tsqr_mi.h): POLICY_AUTO / POLICY_HOUSEHOLDER / POLICY_GRAM."""
+    """R-factor engine policy (include/tsqr_mi.h)."""
     lib().tsqr_mi_set_policy(int(policy))
 
 

@@ -56,3 +56,80 @@ int tsqr_selftest_mfma_f32(float* d, const float* a, const float* b) { hipLaunch
 int tsqr_selftest_mfma_bf16(float* d, const float* a, const float* b) { hipLaunchKernelGGL(mfma_bf16_kernel, dim3(1), dim3(64), 0, 0, d, a, b); return (int)hipDeviceSynchronize(); }
 int tsqr_selftest_split(float* out, const float* in, int n) { hipLaunchKernelGGL(split_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, out, in, n); return (int)hipDeviceSynchronize(); }
 }
+
+// ---- micro-benchmark of chol_kernel (ms per launch; gsum = summed Gram tiles in accumulator order) ----
+extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, const double* gsum, int n, int NT, int reps) {
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT);
+	hipEventRecord(e0, 0);
+	for (int i = 0; i < reps; i++)
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0.f;
+	hipEventElapsedTime(&ms, e0, e1);
+	return ms / reps;
+}
+
+// ---- copy kernel in the (c,q) chunk layout: the HBM ceiling of load_chunk + 16-B-per-lane stores ----
+template <int MODE>
+__global__ __launch_bounds__(256) void copy_cq_kernel(float* q, const float* a, size_t ld, size_t m, int nchunks, int cpw, int nwaves) {
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = blockIdx.x * 4 + wv;
+	if (gw >= nwaves) return;
+	const int c = lane & 15, qq = lane >> 4;
+	const int ch_end = min(nchunks, (gw + 1) * cpw);
+	for (int ch = gw * cpw; ch < ch_end; ch++) {
+		const size_t row0 = (size_t)ch * 64;
+		float p[4][16];
+		if (MODE == 0) {
+			tsqrmi::load_chunk<4>(p, a, ld, row0, m, 64, c, qq);
+		} else {   // MODE 1: 128-B lines per instruction: lane l -> column (l >> 3) + 8*g, rows 4*(l & 7) .. within 32-row halves
+#pragma unroll
+			for (int g = 0; g < 8; g++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const int col = 8 * g + (lane >> 3);
+					const tsqrmi::f32x4u v = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)col * ld + row0 + 32 * h + 4 * (lane & 7));
+					p[g >> 1][8 * (g & 1) + 4 * h + 0] = v[0]; p[g >> 1][8 * (g & 1) + 4 * h + 1] = v[1];
+					p[g >> 1][8 * (g & 1) + 4 * h + 2] = v[2]; p[g >> 1][8 * (g & 1) + 4 * h + 3] = v[3];
+				}
+		}
+		if (MODE == 0) {
+#pragma unroll
+			for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+				for (int rt = 0; rt < 4; rt++) {
+					tsqrmi::f32x4 v = {p[ct][4 * rt], p[ct][4 * rt + 1], p[ct][4 * rt + 2], p[ct][4 * rt + 3]};
+					*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)(16 * ct + c) * ld + row0 + 16 * rt + 4 * qq) = v;
+				}
+		} else {
+#pragma unroll
+			for (int g = 0; g < 8; g++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const int col = 8 * g + (lane >> 3);
+					tsqrmi::f32x4 v = {p[g >> 1][8 * (g & 1) + 4 * h + 0], p[g >> 1][8 * (g & 1) + 4 * h + 1],
+					                   p[g >> 1][8 * (g & 1) + 4 * h + 2], p[g >> 1][8 * (g & 1) + 4 * h + 3]};
+					*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + 32 * h + 4 * (lane & 7)) = v;
+				}
+		}
+	}
+}
+extern "C" float tsqr_selftest_copy_time(float* q, const float* a, size_t m, int mode, int waves, int reps) {
+	const int nch = (int)(m / 64);
+	const int cpw = (nch + waves - 1) / waves;
+	const int nwaves = (nch + cpw - 1) / cpw;
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	for (int it = 0; it < reps + 1; it++) {
+		if (it == 1) (void)hipEventRecord(e0, 0);
+		if (mode == 0) hipLaunchKernelGGL(copy_cq_kernel<0>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
+		else hipLaunchKernelGGL(copy_cq_kernel<1>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
+	}
+	(void)hipEventRecord(e1, 0);
+	(void)hipEventSynchronize(e1);
+	float ms = 0.f;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	return ms / reps;
+}

@@ -276,6 +276,35 @@ __global__ __launch_bounds__(256, TSQR_FOLD_WAVES_PER_SIMD) void fold_kernel(con
 	}
 }
 
+// ---- bf16 split helpers (shared by the Gram and apply kernels) ----
+__device__ __forceinline__ unsigned f2bf(float x) {    // round-to-nearest-even bf16 bits (finite inputs)
+	const unsigned u = __builtin_bit_cast(unsigned, x);
+	return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+	h = f2bf(x);
+	const float r1 = x - __builtin_bit_cast(float, h << 16);
+	m = f2bf(r1);
+	const float r2 = r1 - __builtin_bit_cast(float, m << 16);
+	l = f2bf(r2);
+}
+
+// the same 3-way split for a PAIR of values with v_cvt_pk_bf16_f32 (RNE); results are packed MFMA operand dwords
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+	const f32x2_t v = {a, b};
+	return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+	h = cvt_pk_bf16(a, b);
+	const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+	m = cvt_pk_bf16(ra, rb);
+	const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+	l = cvt_pk_bf16(sa, sb);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Gram engine (R-factor engine of fp32_tc_cor):  G = A^T A on the fp64 matrix cores, R = chol(G) in fp64.
 // Products of fp32 inputs are exact in fp64 and the accumulation is fp64, so R is as backward-accurate as an fp32
@@ -357,6 +386,95 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 	}
 }
 
+// gram_bf16_kernel: the same Gram tiles on v_mfma_f32_16x16x32_bf16 with the 3-way bf16 split of both operands
+// (six exact-product terms per tile, fp32 accumulation over the wave's strip, fp64 from there on).  Memory-bound;
+// the host accepts its result only when the Cholesky pivots show nearly orthogonal columns (chol_kernel threshold).
+// Partials use the f32 MFMA C/D layout (row = 4*(lane>>4) + reg).
+template <int NT>
+__global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
+	constexpr int NTRI = (NT * (NT + 1)) / 2;
+	__shared__ double red[2][NTRI * 256];
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int gw = blockIdx.x * 4 + wv;
+	const int c = lane & 15, q = lane >> 4;
+	f32x4 acc[NTRI];
+#pragma unroll
+	for (int t = 0; t < NTRI; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+	if (gw < a.nwaves) {
+		float p[NT][16];
+		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
+		for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+			load_chunk<NT>(p, a.a, a.lda, (size_t)ch * 64, a.m, a.n, c, q);
+#pragma unroll
+			for (int kt = 0; kt < 2; kt++) {             // K-step of 32 rows: registers 8kt .. 8kt+7 of every lane
+				bf16x8 oh[NT], om[NT], ol[NT];
+#pragma unroll
+				for (int t = 0; t < NT; t++) {
+					u32x4 hh, mm, ll;
+#pragma unroll
+					for (int jp = 0; jp < 4; jp++) {
+						unsigned h, m, lo;
+						split3_pair(p[t][8 * kt + 2 * jp], p[t][8 * kt + 2 * jp + 1], h, m, lo);
+						hh[jp] = h; mm[jp] = m; ll[jp] = lo;
+					}
+					oh[t] = __builtin_bit_cast(bf16x8, hh);
+					om[t] = __builtin_bit_cast(bf16x8, mm);
+					ol[t] = __builtin_bit_cast(bf16x8, ll);
+				}
+				// smallest terms first inside each pass over the tiles; consecutive MFMAs hit different accumulators
+#pragma unroll
+				for (int pass = 0; pass < 6; pass++) {
+					int idx = 0;
+#pragma unroll
+					for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+						for (int tj = ti; tj < NT; tj++) {
+							const bf16x8 av = (pass == 0 || pass == 4) ? om[ti] : ((pass == 2) ? ol[ti] : oh[ti]);
+							const bf16x8 bv = (pass == 0 || pass == 3) ? om[tj] : ((pass == 1) ? ol[tj] : oh[tj]);
+							acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[idx], 0, 0, 0);
+							idx++;
+						}
+				}
+			}
+		}
+	}
+	// workgroup sum in fp64: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the partial
+	double dacc[NTRI][4];
+#pragma unroll
+	for (int t = 0; t < NTRI; t++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) dacc[t][r] = (double)acc[t][r];
+	if (wv >= 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[wv - 2][(t * 4 + r) * 64 + lane] = dacc[t][r];
+	}
+	__syncthreads();
+	if (wv < 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) dacc[t][r] += red[wv][(t * 4 + r) * 64 + lane];
+	}
+	__syncthreads();
+	if (wv == 1) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[0][(t * 4 + r) * 64 + lane] = dacc[t][r];
+	}
+	__syncthreads();
+	if (wv == 0) {
+		double* out = a.part + (size_t)blockIdx.x * NTRI * 256;
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = dacc[t][r] + red[0][(t * 4 + r) * 64 + lane];
+	}
+}
+
 // sub[s][e] = sum of part[b][e] over b = s, s+NSPLIT, ...   (e < nelem)
 __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ sub, const double* __restrict__ part,
                                                           int nblocks, int nelem, int nsplit) {
@@ -375,93 +493,153 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ s
 	sub[(size_t)sidx * nelem + e] = (s0 + s1) + (s2 + s3);
 }
 
+// chol_kernel: sub-sums -> G (fp64) -> R = chol(G) and M = R^-T by the same row operations (forward elimination of
+// [R^T | I]), all in fp64.  Thread (w = wave, j = lane) owns column j and the rows i = w + 4 s of both G and M in
+// registers; step k: the wave owning row k scales it with 1/sqrt(pivot) (v_rsq_f64 + two Newton steps) and publishes
+// the row through LDS (double buffered: one barrier per step), then every wave updates its rows i > k.
 // status[0]: 0 ok, 1 breakdown (a pivot fell below 2^-40 of its diagonal entry: cond(A)^2 is beyond fp64 Cholesky)
 // status[1]: bit pattern of the smallest pivot ratio (float) for diagnostics
-__global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
-                                                   const double* __restrict__ sub, int nsplit, int n, int NT) {
-	__shared__ double Gs[64 * 65];               // symmetric G, then R in the upper triangle: Gs[row * 65 + col]
-	__shared__ double Zs[64 * 65];               // Z = inverse(R): Zs[col * 65 + row]
-	__shared__ double dg[64];
-	__shared__ float minratio[4];
-	const int t = threadIdx.x;
-	const int NP = 16 * NT;
-	const int ntri = (NT * (NT + 1)) / 2;
-	const int nelem = ntri * 256;
-	for (int i = t; i < 64 * 65; i += 256) { Gs[i] = 0.0; Zs[i] = 0.0; }
-	__syncthreads();
-	{
-		int idx = 0;
-		for (int ti = 0; ti < NT; ti++)
-			for (int tj = ti; tj < NT; tj++, idx++)
-				for (int e = t; e < 256; e += 256) {
-					const int reg = e >> 6, l = e & 63;
-					double v = 0.0;
-					for (int sidx = 0; sidx < nsplit; sidx++) v += sub[(size_t)sidx * nelem + idx * 256 + e];
-					const int row = 16 * ti + (l >> 4) + 4 * reg;      // f64 MFMA C/D layout: row = (lane>>4) + 4*reg, col = lane&15
-					const int col = 16 * tj + (l & 15);
-					Gs[row * 65 + col] = v;
-					Gs[col * 65 + row] = v;
-				}
+__device__ __forceinline__ double bcast_lane_f64(double x, int lane_const) {
+	const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+	const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, lane_const);
+	const unsigned hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), lane_const);
+	return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// second reduction stage: G[e] = sum over the nsplit sub-sums (fixed order)
+__global__ __launch_bounds__(256) void gram_reduce2_kernel(double* __restrict__ gout, const double* __restrict__ sub, int nelem, int nsplit) {
+	const int e = blockIdx.x * 256 + threadIdx.x;
+	if (e >= nelem) return;
+	double v[16];
+#pragma unroll
+	for (int s = 0; s < 16; s++) v[s] = (s < nsplit) ? sub[(size_t)s * nelem + e] : 0.0;
+	gout[e] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+	          (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+}
+
+// one elimination step; U = K & 3 is the wave that owns row K; after the rotation of the previous groups row K sits in
+// g[0] / mm[0] of that wave (g[s] <-> row w + 4 (kk + s)).  Nothing on the pivot path reads memory.
+template <int U>
+__device__ __forceinline__ void chol_step(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* __restrict__ z,
+                                          double* pv, int w, int j, int n, int NP, int kk) {
+	const int K = 4 * kk + U;
+	if (K >= n) return;                                  // uniform over the workgroup (the barrier below included)
+	double* rr = Rrow + (U & 1) * 64;
+	double* mr = Mrow + (U & 1) * 64;
+	if (w == U) {
+		const double piv0 = bcast_lane_f64(g[0], K);
+		const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; the breakdown is flagged from pv[] afterwards
+		double y = __builtin_amdgcn_rsq(piv);
+		y = y * (1.5 - 0.5 * piv * y * y);
+		y = y * (1.5 - 0.5 * piv * y * y);
+		const double rk = (j > K) ? g[0] * y : ((j == K) ? piv * y : 0.0);
+		const double mk = mm[0] * y;
+		rr[j] = rk;
+		mr[j] = mk;
+		Rf[K * 65 + j] = (float)rk;
+		if (j == 0) pv[K] = piv0;
+		if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mk : 0.0f;     // Z[j][K] = M[K][j]
 	}
 	__syncthreads();
-	if (t < 64) dg[t] = Gs[t * 65 + t];
-	float worst = 1.0f;
-	__syncthreads();
-	// right-looking Cholesky, G = R^T R; thread owns column j = t & 63 and rows i = (t >> 6) + 4 s
-	const int j = t & 63, ib = t >> 6;
-	for (int k = 0; k < n; k++) {
-		double piv = Gs[k * 65 + k];
-		const double d0 = dg[k];
-		const float ratio = (d0 > 0.0) ? (float)(piv / d0) : 0.0f;
-		worst = fminf(worst, ratio);
-		if (!(piv > d0 * 9.094947017729282e-13)) piv = (d0 > 0.0 ? d0 : 1.0) * 9.094947017729282e-13;   // 2^-40: keep going, flagged
-		const double rkk = sqrt(piv);
-		const double rinv = 1.0 / rkk;
-		__syncthreads();
-		if (t == 0) Gs[k * 65 + k] = rkk;
-		if (t > k && t < n) Gs[k * 65 + t] *= rinv;         // row k of R
-		__syncthreads();
-		if (j > k && j < n) {
-			const double rkj = Gs[k * 65 + j];
-#pragma unroll 4
-			for (int s = 0; s < 16; s++) {
-				const int i = ib + 4 * s;
-				if (i > k && i <= j) Gs[i * 65 + j] -= Gs[k * 65 + i] * rkj;
+	const double rkj = rr[j], mkc = mr[j];
+	const int nlive = 16 - kk;                           // register rows that still exist
+	// branch-free inside a group of four: finished rows get a zero multiplier, all LDS reads issue back to back
+#pragma unroll
+	for (int gq = 0; gq < 4; gq++) {
+		if (4 * gq < nlive) {
+			double rki[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int s = 4 * gq + u;
+				const int i = w + 4 * (kk + s);
+				const double v = rr[min(i, 63)];
+				rki[u] = (i > K && i < 64) ? v : 0.0;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int s = 4 * gq + u;
+				g[s] = fma(-rki[u], rkj, g[s]);
+				mm[s] = fma(-rki[u], mkc, mm[s]);
 			}
 		}
-		__syncthreads();
 	}
-	// breakdown flag
-	for (int o = 32; o > 0; o >>= 1) worst = fminf(worst, __shfl_xor(worst, o));
-	if ((t & 63) == 0) minratio[t >> 6] = worst;
+}
+
+__global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
+                                                   const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio) {
+	__shared__ double Gs[64 * 65];               // symmetric G (assembly only): Gs[row * 65 + col]
+	__shared__ float Rf[64 * 65];                // R rows for the final store
+	__shared__ double Rrow[2 * 64], Mrow[2 * 64], dg[64], pv[64];
+	const int t = threadIdx.x;
+	const int j = t & 63, w = t >> 6;
+	const int NP = 16 * NT;
+	// issue the loads of G first (one value per thread and tile), then initialise LDS while they are in flight
+	double gv[10];
+	{
+		int idx = 0;
+		for (int ti = 0; ti < 4; ti++)
+			for (int tj = ti; tj < 4; tj++) {
+				if (ti < NT && tj < NT) { gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = gsum[idx * 256 + t]; idx++; }
+				else gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = 0.0;
+			}
+	}
+	for (int i = t; i < 64 * 65; i += 256) { Gs[i] = 0.0; Rf[i] = 0.0f; }
+	for (int e = n * NP + t; e < NP * NP; e += 256) z[e] = 0.0f;          // padding rows of Z
 	__syncthreads();
-	if (t == 0) {
-		const float w = fminf(fminf(minratio[0], minratio[1]), fminf(minratio[2], minratio[3]));
-		status[0] = (w > 9.094947017729282e-13f) ? 0u : 1u;
-		status[1] = __builtin_bit_cast(unsigned, w);
+	{
+		const int reg = t >> 6, l = t & 63;
+#pragma unroll
+		for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+			for (int tj = ti; tj < 4; tj++) {
+				if (ti < NT && tj < NT) {
+					// C/D layouts: f64 MFMA row = (lane>>4) + 4*reg, f32/bf16 MFMA row = 4*(lane>>4) + reg; col = lane&15
+					const int row = 16 * ti + (f32_layout ? 4 * (l >> 4) + reg : (l >> 4) + 4 * reg);
+					const int col = 16 * tj + (l & 15);
+					const double v = gv[ti * 4 + tj - (ti * (ti + 1)) / 2];
+					// a diagonal tile holds (i,j) and (j,i); in the bf16-split Gram matrix they can differ by an ulp (cross terms
+					// are added in opposite order), so only the upper-triangle owner writes both mirror positions
+					if (row <= col) {
+						Gs[row * 65 + col] = v;
+						Gs[col * 65 + row] = v;
+					}
+				}
+			}
+	}
+	__syncthreads();
+	double g[16], mm[16];
+#pragma unroll
+	for (int s = 0; s < 16; s++) {
+		const int i = w + 4 * s;
+		g[s] = Gs[i * 65 + j];
+		mm[s] = (i == j) ? 1.0 : 0.0;
+	}
+	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; }
+	__syncthreads();
+#pragma unroll 1
+	for (int kk = 0; kk < 16; kk++) {
+		static_for<0, 4>([&](auto u) { chol_step<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, z, pv, w, j, n, NP, kk); });
+#pragma unroll
+		for (int s = 0; s < 15; s++) { g[s] = g[s + 1]; mm[s] = mm[s + 1]; }   // next group's rows move to slot 0
+	}
+	__syncthreads();
+	// status[0]: 0 ok, 1 rejected: a pivot fell below min_ratio of its diagonal entry (2^-40 for the fp64 Gram matrix:
+	//            cond(A)^2 beyond fp64 Cholesky; 2^-5 for the bf16-split Gram matrix: its fp32 accumulation is only
+	//            good enough for nearly orthogonal columns)
+	// status[1]: bit pattern of the smallest pivot ratio (float) for diagnostics
+	if (w == 0) {
+		const double d0 = dg[j], p0 = pv[j];
+		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
+		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
+		if (j == 0) {
+			status[0] = (ratio > min_ratio) ? 0u : 1u;
+			status[1] = __builtin_bit_cast(unsigned, ratio);
+		}
 	}
 	// R out (fp32, exact zeros below the diagonal)
 	for (int e = t; e < n * n; e += 256) {
 		const int i = e % n, jj = e / n;
-		r[(size_t)jj * ldr + i] = (i <= jj) ? (float)Gs[i * 65 + jj] : 0.0f;
-	}
-	// Z = inverse(R): 4 threads per column (jz = t >> 2, part s = t & 3), back substitution from the diagonal upwards
-	{
-		const int jz = t >> 2, sp = t & 3;
-		for (int i = n - 1; i >= 0; i--) {
-			double partial = 0.0;
-			if (jz < n && i < jz)
-				for (int k = i + 1 + sp; k <= jz; k += 4) partial += Gs[i * 65 + k] * Zs[jz * 65 + k];
-			partial += __shfl_xor(partial, 1);
-			partial += __shfl_xor(partial, 2);
-			if (sp == 0 && jz < n && i <= jz) Zs[jz * 65 + i] = ((i == jz ? 1.0 : 0.0) - partial) / Gs[i * 65 + i];
-			__builtin_amdgcn_wave_barrier();
-		}
-	}
-	__syncthreads();
-	for (int e = t; e < NP * NP; e += 256) {
-		const int i = e % NP, jj = e / NP;
-		z[(size_t)jj * NP + i] = (i <= jj && jj < n) ? (float)Zs[jj * 65 + i] : 0.0f;
+		r[(size_t)jj * ldr + i] = (i <= jj) ? Rf[i * 65 + jj] : 0.0f;
 	}
 }
 
@@ -511,22 +689,10 @@ struct ApplyArgs {
 	int nchunks; int cpw; int nwaves;
 };
 
-__device__ __forceinline__ unsigned f2bf(float x) {    // round-to-nearest-even bf16 bits (finite inputs)
-	const unsigned u = __builtin_bit_cast(unsigned, x);
-	return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-	h = f2bf(x);
-	const float r1 = x - __builtin_bit_cast(float, h << 16);
-	m = f2bf(r1);
-	const float r2 = r1 - __builtin_bit_cast(float, m << 16);
-	l = f2bf(r2);
-}
-
 template <int ENGINE, int NT>
 __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 	constexpr int NP = 16 * NT;
-	constexpr int AS = 68;                               // column stride (floats) of the per-wave A tile
+	constexpr int AS = 20;                               // column stride (floats) of the per-wave 16-row A slab
 	constexpr int ZS = NP + 16;                          // row stride of the fp32 Z image
 	constexpr int KT = (NP + 31) / 32;                   // K-steps of 32 for the bf16 engine
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -566,31 +732,28 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
 	for (int ch = gw * a.cpw; ch < ch_end; ch++) {
 		const size_t row0 = (size_t)ch * 64;
-		{
-			float p[NT][16];
-			load_chunk<NT>(p, a.a, a.lda, row0, a.m, a.n, c, q);
-#pragma unroll
-			for (int ct = 0; ct < NT; ct++)
-#pragma unroll
-				for (int rt = 0; rt < 4; rt++) {
-					f32x4 v = {p[ct][4 * rt], p[ct][4 * rt + 1], p[ct][4 * rt + 2], p[ct][4 * rt + 3]};
-					*reinterpret_cast<f32x4*>(&At[(16 * ct + c) * AS + 16 * rt + 4 * q]) = v;
-				}
-		}
-		__builtin_amdgcn_wave_barrier();
+		float p[NT][16];
+		load_chunk<NT>(p, a.a, a.lda, row0, a.m, a.n, c, q);
 		const bool full = (row0 + 64 <= a.m);
-#pragma unroll 1
+#pragma unroll
 		for (int rt = 0; rt < 4; rt++) {
+			// transpose one 16-row slab through LDS: (c,q) layout -> lane <-> row
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int ct = 0; ct < NT; ct++) {
+				const f32x4 v = {p[ct][4 * rt], p[ct][4 * rt + 1], p[ct][4 * rt + 2], p[ct][4 * rt + 3]};
+				*reinterpret_cast<f32x4*>(&At[(16 * ct + c) * AS + 4 * q]) = v;
+			}
+			__builtin_amdgcn_wave_barrier();
 			f32x4 acc[NT];
 #pragma unroll
 			for (int ct = 0; ct < NT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-			const int arow = 16 * rt + c;                 // A operand: lane&15 <-> row inside the 16-row tile
 			if constexpr (ENGINE == 0) {
 				const float* Zs = reinterpret_cast<const float*>(zbase);
 #pragma unroll
 				for (int t = 0; t < NP / 4; t++) {
 					const int k = 4 * t + q;
-					const float av = At[k * AS + arow];
+					const float av = At[k * AS + c];
 #pragma unroll
 					for (int ct = 0; ct < NT; ct++) {
 						if (4 * t <= 16 * ct + 15) {          // Z[k][j] = 0 for k > j
@@ -601,50 +764,63 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 				}
 			} else {
 				const unsigned short* Zb = reinterpret_cast<const unsigned short*>(zbase);
+				constexpr int PS = KT * NT * 512;             // shorts per part
 				bf16x8 ah[KT], am[KT], al[KT];
 #pragma unroll
 				for (int kt = 0; kt < KT; kt++) {
+					u32x4 hh, mm, ll;
 #pragma unroll
-					for (int jj = 0; jj < 8; jj++) {
-						const int k = 32 * kt + 8 * q + jj;
-						const float v = (k < NP) ? At[k * AS + arow] : 0.0f;
+					for (int jp = 0; jp < 4; jp++) {
+						const int k0 = 32 * kt + 8 * q + 2 * jp;
+						const float v0 = (k0 < NP) ? At[k0 * AS + c] : 0.0f;
+						const float v1 = (k0 + 1 < NP) ? At[(k0 + 1) * AS + c] : 0.0f;
 						unsigned h, m, lo;
-						split3(v, h, m, lo);
-						ah[kt][jj] = (short)h; am[kt][jj] = (short)m; al[kt][jj] = (short)lo;
+						split3_pair(v0, v1, h, m, lo);
+						hh[jp] = h; mm[jp] = m; ll[jp] = lo;
 					}
+					ah[kt] = __builtin_bit_cast(bf16x8, hh);
+					am[kt] = __builtin_bit_cast(bf16x8, mm);
+					al[kt] = __builtin_bit_cast(bf16x8, ll);
 				}
-				constexpr int PS = KT * NT * 512;             // shorts per part
-#pragma unroll
-				for (int ct = 0; ct < NT; ct++) {
-					bf16x8 bh[KT], bm[KT], bl[KT];
-#pragma unroll
-					for (int kt = 0; kt < KT; kt++) {
-						if (32 * kt <= 16 * ct + 15) {
-							const int o = ((kt * NT + ct) * 64 + lane) * 8;
-							bh[kt] = *reinterpret_cast<const bf16x8*>(&Zb[0 * PS + o]);
-							bm[kt] = *reinterpret_cast<const bf16x8*>(&Zb[1 * PS + o]);
-							bl[kt] = *reinterpret_cast<const bf16x8*>(&Zb[2 * PS + o]);
-						}
-					}
-					f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-					for (int kt = 0; kt < KT; kt++)
-						if (32 * kt <= 16 * ct + 15) {
-							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[kt], bm[kt], s, 0, 0, 0);
-							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kt], bl[kt], s, 0, 0, 0);
-							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kt], bh[kt], s, 0, 0, 0);
-						}
-#pragma unroll
-					for (int kt = 0; kt < KT; kt++)
-						if (32 * kt <= 16 * ct + 15) {
-							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kt], bm[kt], s, 0, 0, 0);
-							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[kt], bh[kt], s, 0, 0, 0);
-						}
-#pragma unroll
-					for (int kt = 0; kt < KT; kt++)
-						if (32 * kt <= 16 * ct + 15)
-							s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kt], bh[kt], s, 0, 0, 0);
-					acc[ct] = s;
+				// (kt, ct) pairs with a non-zero Z block, two at a time so consecutive MFMAs hit different accumulators;
+				// inside a pair the small terms go first: (mid*mid, hi*lo, lo*hi), (hi*mid, mid*hi), hi*hi
+				auto pair = [&](auto KTc, auto CTc, auto KTd, auto CTd) {
+					constexpr int k0 = decltype(KTc)::value, c0 = decltype(CTc)::value;
+					constexpr int k1 = decltype(KTd)::value, c1 = decltype(CTd)::value;
+					const int o0 = ((k0 * NT + c0) * 64 + lane) * 8, o1 = ((k1 * NT + c1) * 64 + lane) * 8;
+					const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(&Zb[0 * PS + o0]);
+					const bf16x8 bm0 = *reinterpret_cast<const bf16x8*>(&Zb[1 * PS + o0]);
+					const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(&Zb[2 * PS + o0]);
+					const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(&Zb[0 * PS + o1]);
+					const bf16x8 bm1 = *reinterpret_cast<const bf16x8*>(&Zb[1 * PS + o1]);
+					const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(&Zb[2 * PS + o1]);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k0], bm0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k1], bm1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bl0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bl1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k0], bh0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k1], bh1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bm0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bm1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k0], bh0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k1], bh1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bh0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bh1, acc[c1], 0, 0, 0);
+				};
+				using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+				using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+				if constexpr (NT == 1) {
+					pair(I0{}, I0{}, I0{}, I0{});             // one block only: second half accumulates the same products again ...
+					acc[0] = acc[0] * 0.5f;                   // ... so halve (exact); NT == 1 is not a performance case
+				} else if constexpr (NT == 2) {
+					pair(I0{}, I0{}, I0{}, I1{});
+				} else if constexpr (NT == 3) {
+					pair(I0{}, I0{}, I0{}, I1{});
+					pair(I0{}, I2{}, I1{}, I2{});             // same accumulator twice: chains serialise, still correct
+				} else {
+					pair(I0{}, I0{}, I0{}, I1{});
+					pair(I0{}, I2{}, I0{}, I3{});
+					pair(I1{}, I2{}, I1{}, I3{});
 				}
 			}
 			// D layout: col = lane&15, rows 4*(lane>>4) + i of this 16-row tile
@@ -663,7 +839,6 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 				}
 			}
 		}
-		__builtin_amdgcn_wave_barrier();
 	}
 }
 

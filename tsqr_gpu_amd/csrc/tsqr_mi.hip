@@ -28,7 +28,9 @@ thread_local std::string g_last_error;
 int g_level0_waves = 2048;
 int g_tree_cpw = 4;
 int g_policy = 0;        // 0 auto (fp32_tc_cor: Gram engine with Householder fallback; fp32_notc: Householder), 1 Householder, 2 Gram
-int g_last_engine = 0;   // 0 Householder TSQR, 1 Gram/Cholesky, 2 Gram broke down -> Householder fallback
+int g_last_engine = 0;   // 0 Householder TSQR, 1 fp64 Gram/Cholesky, 2 Gram broke down -> Householder fallback, 3 bf16-split Gram
+int g_min_level = 2;     // lowest R-factor engine level the last call ended up using (2 bf16 Gram, 1 fp64 Gram, 0 Householder)
+int g_gram_level = 2;    // first Gram level tried: 2 bf16-split (then fp64), 1 fp64 only
 constexpr int GRAM_NSPLIT = 16;
 constexpr int GRAM_WAVES = 2048;
 
@@ -149,7 +151,7 @@ WqLayout wq_layout(size_t m, size_t n) {
 	L.r1 = o; o += n * n;
 	L.r2 = o; o += n * n;
 	o = (o + 63) & ~(size_t)63;
-	L.gsub = o; o += (size_t)GRAM_NSPLIT * 10 * 256 * 2;
+	L.gsub = o; o += (size_t)(GRAM_NSPLIT + 1) * 10 * 256 * 2;
 	L.status = o; o += 64;
 	L.total = o;
 	return L;
@@ -196,13 +198,15 @@ int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n
 	return 0;
 }
 
-template <int NT> void launch_gram(const tsqrmi::GramArgs& a, int nblocks, hipStream_t st) {
-	hipLaunchKernelGGL(tsqrmi::gram_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
+template <int NT> void launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool bf16, hipStream_t st) {
+	if (bf16) hipLaunchKernelGGL(tsqrmi::gram_bf16_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
+	else hipLaunchKernelGGL(tsqrmi::gram_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
 }
 
 // Gram engine: R (n x n, ldr) and Z = inverse(R) (NP x NP in z_buf) of src (m x n); status -> wq[L.status]
+// bf16 = true: bf16x3-split Gram matrix (memory-bound, accepted for nearly orthogonal columns only); false: fp64 MFMA
 int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size_t m, size_t n,
-           float* wq, float* wr, const WqLayout& L, hipStream_t st) {
+           float* wq, float* wr, const WqLayout& L, bool bf16, hipStream_t st) {
 	const GramPlan g = gram_plan(m, n);
 	const int NT = (int)(np_of(n) / 16);
 	tsqrmi::GramArgs a{};
@@ -211,10 +215,10 @@ int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size
 	{
 		ProfScope ps(KC_GRAM, st);
 		switch (NT) {
-			case 1: launch_gram<1>(a, g.nblocks, st); break;
-			case 2: launch_gram<2>(a, g.nblocks, st); break;
-			case 3: launch_gram<3>(a, g.nblocks, st); break;
-			default: launch_gram<4>(a, g.nblocks, st); break;
+			case 1: launch_gram<1>(a, g.nblocks, bf16, st); break;
+			case 2: launch_gram<2>(a, g.nblocks, bf16, st); break;
+			case 3: launch_gram<3>(a, g.nblocks, bf16, st); break;
+			default: launch_gram<4>(a, g.nblocks, bf16, st); break;
 		}
 	}
 	HIPCHK(hipGetLastError());
@@ -225,8 +229,11 @@ int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size
 		ProfScope ps(KC_CHOL, st);
 		hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
 		                   sub, a.part, g.nblocks, nelem, nsplit);
+		double* gsum = sub + (size_t)GRAM_NSPLIT * nelem;
+		hipLaunchKernelGGL(tsqrmi::gram_reduce2_kernel, dim3((nelem + 255) / 256), dim3(256), 0, st, gsum, sub, nelem, nsplit);
 		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
-		                   reinterpret_cast<unsigned*>(wq + L.status), sub, nsplit, (int)n, NT);
+		                   reinterpret_cast<unsigned*>(wq + L.status), gsum, (int)n, NT, bf16 ? 1 : 0,
+		                   bf16 ? 0.03125f : 9.094947017729282e-13f);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -234,7 +241,7 @@ int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size
 
 template <int E, int NT> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
 	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
-	const size_t lds = sizeof(float) * 4 * NP * 68 + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)3 * KT * NT * 512 * 2);
+	const size_t lds = sizeof(float) * 4 * NP * 20 + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)3 * KT * NT * 512 * 2);
 	static bool attr_done = false;
 	if (!attr_done) {
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_kernel<E, NT>),
@@ -302,11 +309,11 @@ int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStrea
 
 // R factor (and Q) of one <= 64-column panel.  use_gram: Gram/Cholesky engine, otherwise the Householder TSQR engine.
 // check_now: verify the Gram engine's status immediately (one stream sync) and fall back to Householder on breakdown.
-int panel_qr(int engine, bool use_gram, bool check_now, float* qp, size_t ldq, float* rpp, size_t ldr, const float* ap, size_t lda,
+int panel_qr(int engine, int r_engine, bool check_now, float* qp, size_t ldq, float* rpp, size_t ldr, const float* ap, size_t lda,
              size_t m, size_t c, float* wq, float* wr, const WqLayout& L, unsigned* h_pinned, hipStream_t st) {
 	int rc;
-	if (use_gram) {
-		rc = gram_r(rpp, ldr, wq + L.z, ap, lda, m, c, wq, wr, L, st);
+	for (int e = r_engine; e >= 1; e--) {                // 2: bf16-split Gram, 1: fp64 Gram; with check_now a rejected level escalates
+		rc = gram_r(rpp, ldr, wq + L.z, ap, lda, m, c, wq, wr, L, e == 2, st);
 		if (rc) return rc;
 		bool ok = true;
 		if (check_now) {
@@ -316,18 +323,18 @@ int panel_qr(int engine, bool use_gram, bool check_now, float* qp, size_t ldq, f
 			ok = (status == 0);
 		}
 		if (ok) {
-			g_last_engine = std::max(g_last_engine, 1);
+			g_min_level = std::min(g_min_level, e);
 			return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st, /*z_ready=*/true);
 		}
-		g_last_engine = 2;
 	}
+	g_min_level = 0;
 	rc = fold_r(rpp, ldr, ap, lda, m, c, wq, wr, st);
 	if (rc) return rc;
 	return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st);
 }
 
 // one sweep of 64-wide-panel block QR:  (q, r) <- qr(a);  a is overwritten for n > 64; q may alias a.
-int sweep(int engine, bool use_gram, bool check_now, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n,
+int sweep(int engine, int r_engine, bool check_now, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n,
           float* wq, float* wr, const WqLayout& L, unsigned* h_pinned, hipStream_t st) {
 	const size_t npanels = cdiv(n, PW);
 	for (size_t pi = 0; pi < npanels; pi++) {
@@ -346,7 +353,7 @@ int sweep(int engine, bool use_gram, bool check_now, float* q, size_t ldq, float
 			                   ap, lda, q + B * ldq, ldq, wq + L.s, m, (int)PW, (int)c);
 			HIPCHK(hipGetLastError());
 		}
-		const int rc = panel_qr(engine, use_gram, check_now, q + P * ldq, ldq, r + P * ldr + P, ldr, ap, lda, m, c, wq, wr, L, h_pinned, st);
+		const int rc = panel_qr(engine, r_engine, check_now, q + P * ldq, ldq, r + P * ldr + P, ldr, ap, lda, m, c, wq, wr, L, h_pinned, st);
 		if (rc) return rc;
 	}
 	return 0;
@@ -395,7 +402,16 @@ int tsqr_mi_profile_read(double* ms, long* launches, int max_classes) {
 	return k;
 }
 
-void tsqr_mi_set_policy(int policy) { if (policy >= 0 && policy <= 2) g_policy = policy; }
+void tsqr_mi_set_policy(int policy) {
+	switch (policy) {
+		case 0: g_policy = 0; g_gram_level = 2; break;    // auto
+		case 1: g_policy = 1; g_gram_level = 2; break;    // always Householder TSQR
+		case 2: g_policy = 2; g_gram_level = 1; break;    // always fp64 Gram (no fallback)
+		case 3: g_policy = 2; g_gram_level = 2; break;    // always bf16-split Gram (no check, no fallback)
+		case 4: g_policy = 0; g_gram_level = 1; break;    // auto without the bf16-split level
+		default: break;
+	}
+}
 int tsqr_mi_last_engine(void) { return g_last_engine; }
 
 void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave) {
@@ -422,10 +438,13 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	const bool check_now = may_fall_back && !deferred;
 	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
 	g_last_engine = 0;
+	g_min_level = 2;
 
-	for (int attempt = 0; attempt < 2; attempt++) {
-		const bool gram_now = use_gram && attempt == 0;
-		int rc = sweep(engine, gram_now, check_now, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
+	// R-factor engine levels: 2 bf16-split Gram (memory-bound), 1 fp64 Gram, 0 Householder TSQR.  Deferred mode runs a level
+	// speculatively and steps down when chol_kernel rejected it; with check_now panel_qr escalates per panel by itself.
+	const int first_level = use_gram ? g_gram_level : 0;
+	for (int level = first_level; level >= 0; level--) {
+		int rc = sweep(engine, level, check_now, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
 		if (rc) return rc;
 		if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, st, r, ldr, (int)n);
 		if (reorth) {
@@ -433,21 +452,22 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 			float* r1 = wq + L.r1; float* r2 = wq + L.r2;
 			hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(gb), dim3(256), 0, st, r1, n, r, ldr, (int)n, (int)n);
 			HIPCHK(hipMemsetAsync(r2, 0, sizeof(float) * n * n, st));
-			rc = sweep(engine, gram_now, check_now, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
+			rc = sweep(engine, level, check_now, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
 			if (rc) return rc;
 			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
 		}
 		HIPCHK(hipGetLastError());
-		if (gram_now && deferred) {
+		if (level > 0 && deferred) {
 			unsigned status = 0;
 			rc = read_status(wq, L, h_wl, st, &status);
 			if (rc) return rc;
-			if (status != 0) { g_last_engine = 2; continue; }     // breakdown: redo with the Householder engine
+			if (status != 0) { g_min_level = 2; continue; }       // rejected: step down and redo
 		} else {
 			HIPCHK(hipStreamSynchronize(st));
 		}
 		break;
 	}
+	g_last_engine = !use_gram ? 0 : (g_min_level == 2 ? 3 : (g_min_level == 1 ? 1 : 2));
 	prof_collect();
 	return TSQR_MI_SUCCESS;
 }
