@@ -95,10 +95,15 @@ def main():
     ap.add_argument("--reorth", type=int, default=0)
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gram-waves", type=int, default=0)
+    ap.add_argument("--apply-waves", type=int, default=0)
+    ap.add_argument("--policy", type=int, default=0)
     args = ap.parse_args()
 
     from tsqr_gpu_amd import blockqr as bq
     bq.lib()                                                # fail loudly if the HIP library is missing
+    bq.lib().tsqr_mi_set_tuning2(args.gram_waves, args.apply_waves)
+    bq.set_policy(args.policy)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,25 +183,29 @@ def main():
         dom_ms, dom_launches = prof[dom]
         per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
         # algorithmic work of one launch of the dominant kernel
-        if dom in ("fold_level0", "fold_tree"):
-            alg_flops = f_r(m, n)                           # R factor of the local block: 2MN^2 - 2/3 N^3
-            alg_bytes = 4.0 * m * n
+        if dom == "apply":                                  # Q = A * inverse(R): read A, write Q
+            bound, alg_bytes, alg_flops = "hbm", 8.0 * m * n, 2.0 * m * n * n
+        elif dom == "gram":                                 # G = A^T A: read A once
+            bound, alg_bytes, alg_flops = "hbm", 4.0 * m * n, 2.0 * m * n * n
+        else:                                               # Householder fold: R factor of the local block
+            bound, alg_bytes, alg_flops = "mfma", 4.0 * m * n, f_r(m, n)
+        if bound == "hbm":
+            ach, peak, unit = alg_bytes / per_launch_s / 1e9, PEAK_HBM_TBS * 1e3, "GB/s"
         else:
-            alg_flops = 2.0 * m * n * n                     # Q = A * inverse(R)
-            alg_bytes = 8.0 * m * n
-        ach = alg_flops / per_launch_s / 1e12
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+            ach, peak, unit = alg_flops / per_launch_s / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
+        roofline = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                    "frac": ach / peak, "traffic": None,
                     "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
-                    "hbm_gbs": alg_bytes / per_launch_s / 1e9,
                     "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
-                    "whole_path": {"tflops": gflops / 1e3 / world, "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
+                    "r_factor_engine": bq.ENGINE_NAMES.get(bq.last_engine(), "?"),
+                    "whole_path": {"tflops": gflops / 1e3 / world, "peak_tflops_f32_matrix": PEAK_F32_MATRIX_TFLOPS,
+                                   "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
                                    "algorithmic_gbs": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e9,
                                    "frac_hbm_peak": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e12 / PEAK_HBM_TBS}}
         out = {"metric": "tsqr_gflops", "value": gflops, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32" if args.mode == "fp32_notc" else "f32 (bf16x3-split MFMA, f32 accumulate)",
+               "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": "M=2^%d x N=%d per GPU, %s, reorth=%d, U(-1,1); global %d x %d; F_QR=4MN^2-4/3N^3" % (
                    int(np.log2(m)) if m & (m - 1) == 0 else -1, n, args.mode, args.reorth, m_glob, n),

@@ -9,6 +9,12 @@ for mode in (0, 1):
         ms = L.tsqr_selftest_copy_time(q.data_ptr(), a.data_ptr(), m, mode, waves, 20)
         print('mode %d waves %5d: %.1f us  %.2f TB/s' % (mode, waves, ms * 1e3, 2 * 4 * m * n / ms / 1e9))
     assert torch.equal(a, q)
+L.tsqr_selftest_read_time.restype = ctypes.c_float
+L.tsqr_selftest_read_time.argtypes = L.tsqr_selftest_copy_time.argtypes
+for mode in (0, 1):
+    for waves in (1024, 2048, 3072, 4096, 8192, 16384):
+        ms = L.tsqr_selftest_read_time(q.data_ptr(), a.data_ptr(), m, mode, waves, 20)
+        print('READ mode %d waves %5d: %.1f us  %.2f TB/s' % (mode, waves, ms * 1e3, 4 * m * n / ms / 1e9))
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 q.copy_(a); t0.record()
 for _ in range(20): q.copy_(a)

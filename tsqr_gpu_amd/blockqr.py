@@ -42,7 +42,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_working_reorth_size", "tsqr_mi_batch_size_log2", "tsqr_mi_batch_size",
     "tsqr_mi_qr_f32", "tsqr_mi_local_r_f32", "tsqr_mi_apply_rinv_f32", "tsqr_mi_rmul_f32",
     "tsqr_mi_qr_f32_dist", "tsqr_mi_set_tuning", "tsqr_mi_profile_enable", "tsqr_mi_profile_read",
-    "tsqr_mi_set_policy", "tsqr_mi_last_engine",
+    "tsqr_mi_set_policy", "tsqr_mi_last_engine", "tsqr_mi_set_tuning2",
 ]
 
 _lib = None
@@ -86,6 +86,8 @@ def lib():
     L.tsqr_mi_set_policy.restype = None
     L.tsqr_mi_set_policy.argtypes = [ci]
     L.tsqr_mi_last_engine.restype = ci
+    L.tsqr_mi_set_tuning2.restype = None
+    L.tsqr_mi_set_tuning2.argtypes = [ci, ci]
     L.tsqr_mi_set_tuning.restype = None
     L.tsqr_mi_set_tuning.argtypes = [ci, ci]
     _lib = L

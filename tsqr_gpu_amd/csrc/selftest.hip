@@ -61,10 +61,10 @@ int tsqr_selftest_split(float* out, const float* in, int n) { hipLaunchKernelGGL
 extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, const double* gsum, int n, int NT, int reps) {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT);
+	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f);
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT);
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0.f;
@@ -115,6 +115,54 @@ __global__ __launch_bounds__(256) void copy_cq_kernel(float* q, const float* a, 
 				}
 		}
 	}
+}
+// read-only variants: MODE 0 (c,q) 64-B segments, MODE 1 full 128-B lines per instruction
+template <int MODE>
+__global__ __launch_bounds__(256) void read_cq_kernel(float* out, const float* a, size_t ld, size_t m, int nchunks, int cpw, int nwaves) {
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = blockIdx.x * 4 + wv;
+	if (gw >= nwaves) return;
+	const int c = lane & 15, qq = lane >> 4;
+	const int ch_end = min(nchunks, (gw + 1) * cpw);
+	float acc = 0.f;
+	for (int ch = gw * cpw; ch < ch_end; ch++) {
+		const size_t row0 = (size_t)ch * 64;
+		float p[4][16];
+		if (MODE == 0) {
+			tsqrmi::load_chunk<4>(p, a, ld, row0, m, 64, c, qq);
+		} else {
+#pragma unroll
+			for (int g = 0; g < 8; g++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const int col = 8 * g + (lane >> 3);
+					const tsqrmi::f32x4u v = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)col * ld + row0 + 32 * h + 4 * (lane & 7));
+					p[g >> 1][8 * (g & 1) + 4 * h + 0] = v[0]; p[g >> 1][8 * (g & 1) + 4 * h + 1] = v[1];
+					p[g >> 1][8 * (g & 1) + 4 * h + 2] = v[2]; p[g >> 1][8 * (g & 1) + 4 * h + 3] = v[3];
+				}
+		}
+#pragma unroll
+		for (int t = 0; t < 4; t++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc += p[t][r];
+	}
+	if (acc == 123.456f) out[0] = acc;
+}
+extern "C" float tsqr_selftest_read_time(float* q, const float* a, size_t m, int mode, int waves, int reps) {
+	const int nch = (int)(m / 64);
+	const int cpw = (nch + waves - 1) / waves;
+	const int nwaves = (nch + cpw - 1) / cpw;
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	for (int it = 0; it < reps + 1; it++) {
+		if (it == 1) (void)hipEventRecord(e0, 0);
+		if (mode == 0) hipLaunchKernelGGL(read_cq_kernel<0>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
+		else hipLaunchKernelGGL(read_cq_kernel<1>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
+	}
+	(void)hipEventRecord(e1, 0);
+	(void)hipEventSynchronize(e1);
+	float ms = 0.f;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	return ms / reps;
 }
 extern "C" float tsqr_selftest_copy_time(float* q, const float* a, size_t m, int mode, int waves, int reps) {
 	const int nch = (int)(m / 64);

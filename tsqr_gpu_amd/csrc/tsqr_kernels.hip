@@ -305,6 +305,34 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsig
 	l = cvt_pk_bf16(sa, sb);
 }
 
+// 3-way bf16 split of NPAIR independent pairs, written stage by stage (scheduling barriers in between) so that the
+// NPAIR dependency chains cvt -> unpack -> subtract -> cvt ... overlap instead of running back to back
+template <int NPAIR>
+__device__ __forceinline__ void split3_pairs(const float (&x)[2 * NPAIR], unsigned (&h)[NPAIR], unsigned (&m)[NPAIR], unsigned (&l)[NPAIR]) {
+	float ra[NPAIR], rb[NPAIR];
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) h[i] = cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) {
+		ra[i] = x[2 * i] - __builtin_bit_cast(float, h[i] << 16);
+		rb[i] = x[2 * i + 1] - __builtin_bit_cast(float, h[i] & 0xffff0000u);
+	}
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) m[i] = cvt_pk_bf16(ra[i], rb[i]);
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) {
+		ra[i] -= __builtin_bit_cast(float, m[i] << 16);
+		rb[i] -= __builtin_bit_cast(float, m[i] & 0xffff0000u);
+	}
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) l[i] = cvt_pk_bf16(ra[i], rb[i]);
+	__builtin_amdgcn_sched_barrier(0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Gram engine (R-factor engine of fp32_tc_cor):  G = A^T A on the fp64 matrix cores, R = chol(G) in fp64.
 // Products of fp32 inputs are exact in fp64 and the accumulation is fp64, so R is as backward-accurate as an fp32
@@ -390,6 +418,12 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 // (six exact-product terms per tile, fp32 accumulation over the wave's strip, fp64 from there on).  Memory-bound;
 // the host accepts its result only when the Cholesky pivots show nearly orthogonal columns (chol_kernel threshold).
 // Partials use the f32 MFMA C/D layout (row = 4*(lane>>4) + reg).
+#ifndef TSQR_GRAM_TERMS
+#define TSQR_GRAM_TERMS 6
+#endif
+#ifndef TSQR_GRAM_FLUSH
+#define TSQR_GRAM_FLUSH 4
+#endif
 template <int NT>
 __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
@@ -398,12 +432,19 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	const int wv = threadIdx.x >> 6;
 	const int gw = blockIdx.x * 4 + wv;
 	const int c = lane & 15, q = lane >> 4;
-	f32x4 acc[NTRI];
+	// the MFMA accumulators are flushed into separate fp32 totals (round-to-nearest v_add) every TSQR_GRAM_FLUSH chunks:
+	// the MFMA's own fp32 accumulation is biased (measured: ||Q^T Q - I|| grows with the accumulation length), so the
+	// length of an MFMA accumulation chain must not depend on m
+	f32x4 acc[NTRI], tot[NTRI];
 #pragma unroll
-	for (int t = 0; t < NTRI; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+	for (int t = 0; t < NTRI; t++) {
+		acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+		tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+	}
 	if (gw < a.nwaves) {
 		float p[NT][16];
 		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
+		int since_flush = 0;
 		for (int ch = gw * a.cpw; ch < ch_end; ch++) {
 			load_chunk<NT>(p, a.a, a.lda, (size_t)ch * 64, a.m, a.n, c, q);
 #pragma unroll
@@ -424,7 +465,7 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 				}
 				// smallest terms first inside each pass over the tiles; consecutive MFMAs hit different accumulators
 #pragma unroll
-				for (int pass = 0; pass < 6; pass++) {
+				for (int pass = 6 - TSQR_GRAM_TERMS; pass < 6; pass++) {
 					int idx = 0;
 #pragma unroll
 					for (int ti = 0; ti < NT; ti++)
@@ -437,6 +478,14 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 						}
 				}
 			}
+			if (++since_flush == TSQR_GRAM_FLUSH || ch + 1 == ch_end) {
+				since_flush = 0;
+#pragma unroll
+				for (int t = 0; t < NTRI; t++) {
+					tot[t] += acc[t];
+					acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+				}
+			}
 		}
 	}
 	// workgroup sum in fp64: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the partial
@@ -444,7 +493,7 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 #pragma unroll
 	for (int t = 0; t < NTRI; t++)
 #pragma unroll
-		for (int r = 0; r < 4; r++) dacc[t][r] = (double)acc[t][r];
+		for (int r = 0; r < 4; r++) dacc[t][r] = (double)tot[t][r];
 	if (wv >= 2) {
 #pragma unroll
 		for (int t = 0; t < NTRI; t++)
@@ -766,21 +815,23 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 				const unsigned short* Zb = reinterpret_cast<const unsigned short*>(zbase);
 				constexpr int PS = KT * NT * 512;             // shorts per part
 				bf16x8 ah[KT], am[KT], al[KT];
+				{
+					float x[8 * KT];
+					unsigned hh[4 * KT], mm[4 * KT], ll[4 * KT];
 #pragma unroll
-				for (int kt = 0; kt < KT; kt++) {
-					u32x4 hh, mm, ll;
+					for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-					for (int jp = 0; jp < 4; jp++) {
-						const int k0 = 32 * kt + 8 * q + 2 * jp;
-						const float v0 = (k0 < NP) ? At[k0 * AS + c] : 0.0f;
-						const float v1 = (k0 + 1 < NP) ? At[(k0 + 1) * AS + c] : 0.0f;
-						unsigned h, m, lo;
-						split3_pair(v0, v1, h, m, lo);
-						hh[jp] = h; mm[jp] = m; ll[jp] = lo;
+						for (int e = 0; e < 8; e++) {
+							const int k0 = 32 * kt + 8 * q + e;
+							x[8 * kt + e] = (k0 < NP) ? At[k0 * AS + c] : 0.0f;
+						}
+					split3_pairs<4 * KT>(x, hh, mm, ll);
+#pragma unroll
+					for (int kt = 0; kt < KT; kt++) {
+						ah[kt] = __builtin_bit_cast(bf16x8, u32x4{hh[4 * kt], hh[4 * kt + 1], hh[4 * kt + 2], hh[4 * kt + 3]});
+						am[kt] = __builtin_bit_cast(bf16x8, u32x4{mm[4 * kt], mm[4 * kt + 1], mm[4 * kt + 2], mm[4 * kt + 3]});
+						al[kt] = __builtin_bit_cast(bf16x8, u32x4{ll[4 * kt], ll[4 * kt + 1], ll[4 * kt + 2], ll[4 * kt + 3]});
 					}
-					ah[kt] = __builtin_bit_cast(bf16x8, hh);
-					am[kt] = __builtin_bit_cast(bf16x8, mm);
-					al[kt] = __builtin_bit_cast(bf16x8, ll);
 				}
 				// (kt, ct) pairs with a non-zero Z block, two at a time so consecutive MFMAs hit different accumulators;
 				// inside a pair the small terms go first: (mid*mid, hi*lo, lo*hi), (hi*mid, mid*hi), hi*hi

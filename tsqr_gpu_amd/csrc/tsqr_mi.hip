@@ -32,7 +32,8 @@ int g_last_engine = 0;   // 0 Householder TSQR, 1 fp64 Gram/Cholesky, 2 Gram bro
 int g_min_level = 2;     // lowest R-factor engine level the last call ended up using (2 bf16 Gram, 1 fp64 Gram, 0 Householder)
 int g_gram_level = 2;    // first Gram level tried: 2 bf16-split (then fp64), 1 fp64 only
 constexpr int GRAM_NSPLIT = 16;
-constexpr int GRAM_WAVES = 2048;
+int g_gram_waves = 2048;
+int g_apply_waves = 2048;
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
 enum { KC_FOLD0 = 0, KC_TREE = 1, KC_TRINV = 2, KC_APPLY = 3, KC_COUPLE = 4, KC_MISC = 5, KC_GRAM = 6, KC_CHOL = 7, KC_COUNT = 8 };
@@ -130,7 +131,7 @@ GramPlan gram_plan(size_t m, size_t n) {
 	GramPlan g{};
 	const size_t NT = np_of(n) / 16;
 	g.nch = (int)cdiv(m, 64);
-	g.cpw = (int)std::max<size_t>(1, cdiv((size_t)g.nch, (size_t)GRAM_WAVES));
+	g.cpw = (int)std::max<size_t>(1, cdiv((size_t)g.nch, (size_t)g_gram_waves));
 	g.nwaves = (int)cdiv((size_t)g.nch, (size_t)g.cpw);
 	g.nblocks = (g.nwaves + 3) / 4;
 	g.ntri = (int)(NT * (NT + 1) / 2);
@@ -274,7 +275,7 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
 	tsqrmi::ApplyArgs aa{};
 	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = z_buf;
 	const size_t nch = cdiv(m, 64);
-	const size_t target = 4096;
+	const size_t target = (size_t)g_apply_waves;
 	aa.cpw = (int)std::max<size_t>(1, cdiv(nch, target));
 	aa.nchunks = (int)nch;
 	aa.nwaves = (int)cdiv(nch, (size_t)aa.cpw);
@@ -417,6 +418,10 @@ int tsqr_mi_last_engine(void) { return g_last_engine; }
 void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave) {
 	if (level0_waves > 0) g_level0_waves = level0_waves;
 	if (tree_chunks_per_wave > 1) g_tree_cpw = tree_chunks_per_wave;
+}
+void tsqr_mi_set_tuning2(int gram_waves, int apply_waves) {
+	if (gram_waves > 0) g_gram_waves = gram_waves;
+	if (apply_waves > 0) g_apply_waves = apply_waves;
 }
 
 int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
