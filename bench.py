@@ -84,6 +84,24 @@ def cpu_baseline(n, mode_name, sample_rows):
     return out
 
 
+def pmc_traffic(kernel_class, m, n, mode):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc_hbm_traffic.json:
+    FETCH_SIZE x2 for gfx950, WRITE_SIZE exact -- separate --pmc passes).  Only valid for the workload
+    those passes were taken on (2^20 x 64, fp32_tc_cor); otherwise null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files or m != 1 << 20 or n != 64 or mode != "fp32_tc_cor":
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        for k in data["kernels"].values():
+            if k.get("class") == kernel_class:
+                return k["hbm_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +111,7 @@ def main():
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--mode", default="fp32_tc_cor", choices=["fp32_tc_cor", "fp32_notc"])
     ap.add_argument("--reorth", type=int, default=0)
-    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 15)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 18)   # ~10-20 s of CPU work on the GPU box host
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gram-waves", type=int, default=0)
     ap.add_argument("--apply-waves", type=int, default=0)
@@ -194,7 +212,7 @@ def main():
         else:
             ach, peak, unit = alg_flops / per_launch_s / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
         roofline = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                    "frac": ach / peak, "traffic": None,
+                    "frac": ach / peak, "traffic": pmc_traffic(dom, m, n, args.mode),
                     "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
                     "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
