@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--gram-waves", type=int, default=0)
     ap.add_argument("--apply-waves", type=int, default=0)
     ap.add_argument("--policy", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true", help="use the row-partitioned driver even on one GPU")
     args = ap.parse_args()
 
     from tsqr_gpu_amd import blockqr as bq
@@ -138,7 +139,7 @@ def main():
     d_a = synth_block(m, n, m_glob, rank * m, 0, dev)
     d_q = torch.empty(n, m, dtype=torch.float32, device=dev)
     d_r = torch.zeros(n, n, dtype=torch.float32, device=dev)
-    if world == 1:
+    if world == 1 and not args.force_dist:
         bf = bq.buffer(mode, bool(args.reorth), device=dev)
         bf.allocate(m, n)
 

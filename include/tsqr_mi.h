@@ -78,6 +78,16 @@ int tsqr_mi_local_r_f32(float* r, size_t ldr, const float* a, size_t lda, size_t
 int tsqr_mi_apply_rinv_f32(int mode, float* q, size_t ldq, const float* a, size_t lda,
                            const float* r, size_t ldr, size_t m, size_t n,
                            void* wq, void* stream);
+/* Staged Gram engine for the row-partitioned path.  level 2 = bf16-split Gram matrix, 1 = fp64 Gram matrix.
+ *   tsqr_mi_gram_f32: gsum (tsqr_mi_gram_elems(n) doubles, MFMA-accumulator order) = Gram tiles of the local block;
+ *                     the caller sums gsum over the ranks (all-reduce) before
+ *   tsqr_mi_chol_f32: R = chol(G) into r, inverse(R) into the work buffer, *status_out = 0 accepted / 1 rejected
+ *                     (blocking); m must be the same value as in the other staged calls (it fixes the work-buffer layout)
+ *   tsqr_mi_apply_z_f32: q = a * inverse(R) with the inverse left in wq by tsqr_mi_chol_f32. */
+size_t tsqr_mi_gram_elems(size_t n);
+int tsqr_mi_gram_f32(int level, double* gsum, const float* a, size_t lda, size_t m, size_t n, void* wq, void* wr, void* stream);
+int tsqr_mi_chol_f32(int level, float* r, size_t ldr, const double* gsum, size_t m, size_t n, void* wq, unsigned* status_out, void* stream);
+int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t lda, size_t m, size_t n, void* wq, void* stream);
 /* r (n x n) <- r2 * r (upper triangular product, used after a reorthogonalisation sweep) */
 int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t n, void* wq, void* stream);
 

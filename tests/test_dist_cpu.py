@@ -15,8 +15,29 @@ import torch.multiprocessing as mp
 class NumpyEngine:
     """Test double for dist.HipEngine: same interface, LAPACK arithmetic."""
 
-    def __init__(self, n):
+    def __init__(self, n, use_gram=False, reject_levels=()):
         self.n = n
+        self.use_gram = use_gram
+        self.reject_levels = reject_levels          # Gram levels this double pretends to reject (exercises the escalation)
+        self.last_engine = 0
+        self._z = None
+
+    def gram(self, level, a, lda, m):
+        am = self._cm(a, lda, m, self.n).astype(np.float64)
+        return torch.from_numpy((am.T @ am).reshape(-1).copy())
+
+    def chol(self, level, g, m, r):
+        if level in self.reject_levels:
+            return 1
+        gm = g.numpy().reshape(self.n, self.n)
+        rr = np.linalg.cholesky(gm).T
+        r.copy_(torch.from_numpy(np.ascontiguousarray(rr.T.astype(np.float32))))
+        self._z = np.linalg.inv(rr)
+        return 0
+
+    def apply_z(self, q, ldq, a, lda, m):
+        am = self._cm(a, lda, m, self.n).astype(np.float64)
+        self._cm(q, ldq, m, self.n)[:] = (am @ self._z).astype(np.float32)
 
     @staticmethod
     def _cm(t, ld, m, n):          # column-major m x n view of a tensor
@@ -42,7 +63,7 @@ class NumpyEngine:
         return torch.empty(*shape, dtype=torch.float32)
 
 
-def _worker(rank, world, port, m_local, n, reorth, out):
+def _worker(rank, world, port, m_local, n, reorth, out, use_gram=False, reject=()):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -53,7 +74,8 @@ def _worker(rank, world, port, m_local, n, reorth, out):
     a = torch.from_numpy(np.ascontiguousarray(a_loc.T))
     q = torch.zeros(n, m_local)
     r = torch.zeros(n, n)
-    st = tdist.qr_dist(q, m_local, r, a, m_local, m_local, n, NumpyEngine(n), reorthogonalize=reorth)
+    eng = NumpyEngine(n, use_gram, reject)
+    st = tdist.qr_dist(q, m_local, r, a, m_local, m_local, n, eng, reorthogonalize=reorth)
     rs = [torch.zeros(n, n) for _ in range(world)]
     dist.all_gather(rs, r)
     qs = [torch.zeros(n, m_local) for _ in range(world)]
@@ -61,7 +83,7 @@ def _worker(rank, world, port, m_local, n, reorth, out):
     if rank == 0:
         qg = np.concatenate([t.numpy().T for t in qs], axis=0).astype(np.float64)
         rg = r.numpy().T.astype(np.float64)
-        out.put({"st": st, "r_same": all(torch.equal(rs[0], t) for t in rs),
+        out.put({"engine": eng.last_engine, "st": st, "r_same": all(torch.equal(rs[0], t) for t in rs),
                  "res": float(np.linalg.norm(qg @ rg - a_glob) / np.linalg.norm(a_glob)),
                  "orth": float(np.linalg.norm(qg.T @ qg - np.eye(n))),
                  "lower": float(np.abs(np.tril(rg, -1)).max())})
@@ -73,11 +95,11 @@ def _free_port():
     return p
 
 
-def _run(m_local, n, reorth):
+def _run(m_local, n, reorth, use_gram=False, reject=()):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, m_local, n, reorth, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, m_local, n, reorth, out, use_gram, reject)) for r in range(2)]
     for p in procs:
         p.start()
     res = out.get(timeout=120)
@@ -97,3 +119,13 @@ def test_two_rank_reorth_and_short_blocks():
     res = _run(40, 64, True)      # each rank's block has fewer rows than columns: only the global matrix is tall
     assert res["st"] == 0 and res["r_same"]
     assert res["res"] < 1e-6 and res["orth"] < 1e-5
+
+
+def test_two_rank_gram_engine_and_escalation():
+    res = _run(600, 32, False, use_gram=True)                       # Gram level 2 accepted: all-reduce of G
+    assert res["st"] == 0 and res["r_same"] and res["engine"] == 3
+    assert res["res"] < 1e-6 and res["orth"] < 1e-5 and res["lower"] == 0.0
+    res = _run(600, 32, True, use_gram=True, reject=(2,))           # level 2 rejected on every rank -> fp64 level
+    assert res["st"] == 0 and res["r_same"] and res["engine"] == 1 and res["orth"] < 1e-5
+    res = _run(600, 32, False, use_gram=True, reject=(2, 1))        # both rejected -> Householder all-gather path
+    assert res["st"] == 0 and res["r_same"] and res["engine"] == 2 and res["orth"] < 1e-5

@@ -233,3 +233,23 @@ def test_auto_policy_escalation(bq, oracle, torch_cuda):
         assert np.isfinite(q).all() and oracle.residual(bad, q, r) < 2e-6
         if reorth:
             assert oracle.orthogonality_fro(q) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+@pytest.mark.parametrize("reorth", [False, True])
+def test_dist_driver_single_rank(bq, oracle, torch_cuda, mode, reorth):
+    """The row-partitioned driver with its HIP engine on one rank (no collectives): staged C-ABI entry points
+    (Gram / Cholesky / apply for fp32_tc_cor, fold / apply for fp32_notc)."""
+    torch = torch_cuda
+    from tsqr_gpu_amd import dist as tdist
+    m, n = 20000, 64
+    a = oracle.uniform_matrix(m, n, seed=13)
+    d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+    eng = tdist.HipEngine(bq.compute_mode[mode], m, n, 1)
+    st = tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=reorth)
+    torch.cuda.synchronize()
+    assert st == 0 and eng.last_engine == (3 if mode == "fp32_tc_cor" else 0)
+    q = d_q.cpu().numpy().T; r = d_r.cpu().numpy().T
+    assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL
+    assert np.abs(np.tril(r, -1)).max() == 0.0

@@ -779,7 +779,12 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 
 	float* At = At_all + wv * NP * AS;
 	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
-	for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+	for (int chi = gw * a.cpw; chi < ch_end; chi++) {
+#ifndef TSQR_APPLY_FORWARD
+		const int ch = a.nchunks - 1 - chi;              // last-touched rows of A first (Infinity-Cache reuse after the R pass)
+#else
+		const int ch = chi;
+#endif
 		const size_t row0 = (size_t)ch * 64;
 		float p[NT][16];
 		load_chunk<NT>(p, a.a, a.lda, row0, a.m, a.n, c, q);

@@ -205,9 +205,9 @@ template <int NT> void launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool 
 }
 
 // Gram engine: R (n x n, ldr) and Z = inverse(R) (NP x NP in z_buf) of src (m x n); status -> wq[L.status]
-// bf16 = true: bf16x3-split Gram matrix (memory-bound, accepted for nearly orthogonal columns only); false: fp64 MFMA
-int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size_t m, size_t n,
-           float* wq, float* wr, const WqLayout& L, bool bf16, hipStream_t st) {
+// Gram matrix of src (m x n) in MFMA-accumulator order -> gsum (ntri*256 doubles).  bf16 = true: bf16x3-split MFMA
+// (memory-bound, f32 C/D layout), false: fp64 MFMA (f64 C/D layout).
+int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float* wq, float* wr, const WqLayout& L, bool bf16, hipStream_t st) {
 	const GramPlan g = gram_plan(m, n);
 	const int NT = (int)(np_of(n) / 16);
 	tsqrmi::GramArgs a{};
@@ -230,14 +230,32 @@ int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size
 		ProfScope ps(KC_CHOL, st);
 		hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
 		                   sub, a.part, g.nblocks, nelem, nsplit);
-		double* gsum = sub + (size_t)GRAM_NSPLIT * nelem;
 		hipLaunchKernelGGL(tsqrmi::gram_reduce2_kernel, dim3((nelem + 255) / 256), dim3(256), 0, st, gsum, sub, nelem, nsplit);
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// R = chol(G) (n x n, ldr), Z = inverse(R) (NP x NP in z_buf), status word -> wq[L.status]
+int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t n, float* wq, const WqLayout& L, bool bf16, hipStream_t st) {
+	const int NT = (int)(np_of(n) / 16);
+	{
+		ProfScope ps(KC_CHOL, st);
 		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
 		                   reinterpret_cast<unsigned*>(wq + L.status), gsum, (int)n, NT, bf16 ? 1 : 0,
 		                   bf16 ? 0.03125f : 9.094947017729282e-13f);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
+}
+
+// Gram engine: R (n x n, ldr) and Z = inverse(R) (NP x NP in z_buf) of src (m x n); status -> wq[L.status]
+int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size_t m, size_t n,
+           float* wq, float* wr, const WqLayout& L, bool bf16, hipStream_t st) {
+	double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 10 * 256;
+	const int rc = gram_g(gsum, src, ld, m, n, wq, wr, L, bf16, st);
+	if (rc) return rc;
+	return chol_from_g(r, ldr, z_buf, gsum, n, wq, L, bf16, st);
 }
 
 template <int E, int NT> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
@@ -494,6 +512,39 @@ int tsqr_mi_apply_rinv_f32(int mode, float* q, size_t ldq, const float* a, size_
 	                  reinterpret_cast<hipStream_t>(stream));
 }
 
+// ---- staged Gram engine (row-partitioned multi-GPU path: local Gram -> all-reduce of G -> Cholesky -> apply) ----
+int tsqr_mi_gram_f32(int level, double* gsum, const float* a, size_t lda, size_t m, size_t n, void* wq, void* wr, void* stream) {
+	if (m == 0 || n == 0 || n > PW || (level != 1 && level != 2)) return TSQR_MI_ERROR_INVALID_SIZE;
+	const WqLayout L = wq_layout(m, n);
+	return gram_g(gsum, a, lda, m, n, reinterpret_cast<float*>(wq), reinterpret_cast<float*>(wr), L, level == 2,
+	              reinterpret_cast<hipStream_t>(stream));
+}
+
+int tsqr_mi_chol_f32(int level, float* r, size_t ldr, const double* gsum, size_t m, size_t n, void* wq_v, unsigned* status_out, void* stream) {
+	if (m == 0 || n == 0 || n > PW || (level != 1 && level != 2)) return TSQR_MI_ERROR_INVALID_SIZE;
+	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+	float* wq = reinterpret_cast<float*>(wq_v);
+	const WqLayout L = wq_layout(m, n);
+	int rc = chol_from_g(r, ldr, wq + L.z, gsum, n, wq, L, level == 2, st);
+	if (rc) return rc;
+	unsigned status = 0;
+	rc = read_status(wq, L, nullptr, st, &status);       // blocking: the caller decides on the next level
+	if (rc) return rc;
+	if (status_out) *status_out = status;
+	return 0;
+}
+
+int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t lda, size_t m, size_t n, void* wq_v, void* stream) {
+	if (m == 0 || n == 0 || n > PW) return TSQR_MI_ERROR_INVALID_SIZE;
+	const int engine = engine_of(mode);
+	if (engine < 0) return TSQR_MI_ERROR_UNSUPPORTED;
+	float* wq = reinterpret_cast<float*>(wq_v);
+	const WqLayout L = wq_layout(m, n);
+	return apply_rinv(engine, q, ldq, a, lda, nullptr, 0, m, n, wq + L.z, reinterpret_cast<hipStream_t>(stream), /*z_ready=*/true);
+}
+
+size_t tsqr_mi_gram_elems(size_t n) { const size_t NT = np_of(n) / 16; return NT * (NT + 1) / 2 * 256; }
+
 int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t n, void* wq, void* stream) {
 	if (n == 0) return TSQR_MI_ERROR_INVALID_SIZE;
 	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -507,13 +558,21 @@ int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t 
 
 // ---- RCCL path: the library is resolved lazily so that libtsqr_mi.so loads without librccl ----
 typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static void* rccl_symbol(const char* name) {
+	static void* h = nullptr;
+	if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+	if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+	return h ? dlsym(h, name) : nullptr;
+}
 static nccl_allgather_t resolve_allgather() {
 	static nccl_allgather_t fn = nullptr;
-	if (!fn) {
-		void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-		if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-		if (h) fn = reinterpret_cast<nccl_allgather_t>(dlsym(h, "ncclAllGather"));
-	}
+	if (!fn) fn = reinterpret_cast<nccl_allgather_t>(rccl_symbol("ncclAllGather"));
+	return fn;
+}
+static nccl_allreduce_t resolve_allreduce() {
+	static nccl_allreduce_t fn = nullptr;
+	if (!fn) fn = reinterpret_cast<nccl_allreduce_t>(rccl_symbol("ncclAllReduce"));
 	return fn;
 }
 
@@ -531,8 +590,43 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 	const WqLayout L = wq_layout(std::max(m_local, (size_t)nranks * n), n);
 	float* rl = wq + L.r2;                               // local R, n x n packed (ld n)
 	const float* src = a; size_t ld_src = lda;
+	const bool use_gram = (g_policy == 2) || (g_policy == 0 && mode == TSQR_MI_FP32_TC_COR);
+	nccl_allreduce_t allreduce = use_gram ? resolve_allreduce() : nullptr;
 	for (int it = 0; it < (reorth ? 2 : 1); it++) {
-		int rc = fold_r(rl, n, src, ld_src, m_local, n, wq, wr, st);
+		int rc;
+		if (use_gram && allreduce) {
+			// Gram engine: local Gram tiles -> all-reduce (fp64 sum) -> Cholesky on every rank -> apply; rejected levels step down
+			double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 10 * 256;
+			const size_t gelems = (np_of(n) / 16) * (np_of(n) / 16 + 1) / 2 * 256;
+			bool done = false;
+			for (int level = g_gram_level; level >= 1 && !done; level--) {
+				rc = gram_g(gsum, src, ld_src, m_local, n, wq, wr, L, level == 2, st);
+				if (rc) return rc;
+				// ncclFloat64 == 8, ncclSum == 0 in nccl.h/rccl.h
+				if (allreduce(gsum, gsum, gelems, 8, 0, nccl_comm, st) != 0) { g_last_error = "ncclAllReduce failed"; return -1; }
+				float* rdst = (it == 0) ? r : rl;
+				rc = chol_from_g(rdst, (it == 0) ? ldr : n, wq + L.z, gsum, n, wq, L, level == 2, st);
+				if (rc) return rc;
+				unsigned status = 0;
+				rc = read_status(wq, L, nullptr, st, &status);
+				if (rc) return rc;
+				if (status == 0 || g_policy == 2) {
+					rc = apply_rinv(engine, q, ldq, src, ld_src, nullptr, 0, m_local, n, wq + L.z, st, /*z_ready=*/true);
+					if (rc) return rc;
+					done = true;
+				}
+			}
+			if (done) {
+				if (it == 1) {
+					float* r1 = wq + L.r1;
+					hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(16), dim3(256), 0, st, r1, n, r, ldr, (int)n, (int)n);
+					hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(16), dim3(256), 0, st, r, ldr, rl, n, r1, n, (int)n);
+				}
+				src = q; ld_src = ldq;
+				continue;
+			}
+		}
+		rc = fold_r(rl, n, src, ld_src, m_local, n, wq, wr, st);
 		if (rc) return rc;
 		// ncclFloat32 == 7 in nccl.h/rccl.h
 		if (allgather(rl, gather_buf, n * n, 7, nccl_comm, st) != 0) { g_last_error = "ncclAllGather failed"; return -1; }

@@ -1,12 +1,19 @@
 """Row-partitioned TSQR across the GPUs of one node (new functionality -- the reference
 has no multi-GPU path).
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank p holds the row block A_p:
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank p holds the row block A_p.
+
+Householder engine (fp32_notc; fallback of fp32_tc_cor):
   1. R_p = fold(A_p)                    local streaming Householder TSQR         (tsqr_mi_local_r_f32)
   2. all_gather(R_p)                    the ONLY exchange: n*n floats per rank (16 KiB at n = 64, latency-bound)
   3. R   = fold([R_0; ...; R_{P-1}])    every rank folds the same stack -> R is bitwise identical on all ranks
   4. Q_p = A_p * inverse(R)             local                                    (tsqr_mi_apply_rinv_f32)
-Reorthogonalize=true repeats 1-4 on Q and sets R <- R2 * R.
+Gram engine (fp32_tc_cor, same acceptance levels as the single-GPU path):
+  1. G_p = A_p^T A_p                    local, on the matrix cores               (tsqr_mi_gram_f32)
+  2. all_reduce(G_p)                    the ONLY exchange: <= 2560 doubles (20 KiB at n = 64)
+  3. R = chol(G), Z = inverse(R)        every rank, identical input -> identical R (tsqr_mi_chol_f32); rejected -> next level
+  4. Q_p = A_p * Z                      local                                    (tsqr_mi_apply_z_f32)
+Reorthogonalize=true repeats the sweep on Q and sets R <- R2 * R.
 
 The arithmetic is behind an `engine` object so that the exchange logic can be exercised on CPU with the gloo
 backend and a test double (tests/test_dist_cpu.py); the product engine is HipEngine (C ABI, no CPU fallback).
@@ -20,13 +27,18 @@ from . import blockqr as bq
 class HipEngine:
     """The product engine: staged C-ABI entry points of libtsqr_mi.so on the current HIP stream."""
 
-    def __init__(self, mode, m_local, n, world_size):
+    def __init__(self, mode, m_local, n, world_size, use_gram=None):
         assert n <= 64, "the row-partitioned path factors one 64-wide panel"
         self.mode = bq.compute_mode(mode)
         self.n = n
+        self.m_local = m_local
+        # same default policy as tsqr_mi_qr_f32: Gram engine for fp32_tc_cor, Householder TSQR for fp32_notc
+        self.use_gram = (self.mode == bq.compute_mode.fp32_tc_cor) if use_gram is None else bool(use_gram)
+        self.last_engine = 0
         rows = max(m_local, world_size * n)
         self.wq = torch.empty(max(bq.get_working_q_size(rows, n), 1), dtype=torch.float32, device="cuda")
         self.wr = torch.empty(max(bq.get_working_r_size(rows, n), 1), dtype=torch.float32, device="cuda")
+        self._g = torch.empty(bq.lib().tsqr_mi_gram_elems(n), dtype=torch.float64, device="cuda")
 
     def _stream(self):
         return torch.cuda.current_stream().cuda_stream
@@ -49,6 +61,31 @@ class HipEngine:
         if st != 0:
             raise RuntimeError("tsqr_mi_rmul_f32 -> %d %s" % (st, bq.last_error()))
 
+    def gram(self, level, a, lda, m):
+        """Gram tiles of the local block in MFMA-accumulator order (float64 tensor); level 2 = bf16-split, 1 = fp64."""
+        g = self._g
+        st = bq.lib().tsqr_mi_gram_f32(level, g.data_ptr(), a.data_ptr(), lda, m, self.n,
+                                       self.wq.data_ptr(), self.wr.data_ptr(), self._stream())
+        if st != 0:
+            raise RuntimeError("tsqr_mi_gram_f32 -> %d %s" % (st, bq.last_error()))
+        return g
+
+    def chol(self, level, g, m, r):
+        """r <- chol(G); inverse(R) stays in the work buffer for apply_z.  Returns 0 accepted / 1 rejected (blocking)."""
+        import ctypes
+        status = ctypes.c_uint(0)
+        st = bq.lib().tsqr_mi_chol_f32(level, r.data_ptr(), self.n, g.data_ptr(), m, self.n, self.wq.data_ptr(),
+                                       ctypes.byref(status), self._stream())
+        if st != 0:
+            raise RuntimeError("tsqr_mi_chol_f32 -> %d %s" % (st, bq.last_error()))
+        return int(status.value)
+
+    def apply_z(self, q, ldq, a, lda, m):
+        st = bq.lib().tsqr_mi_apply_z_f32(int(self.mode), q.data_ptr(), ldq, a.data_ptr(), lda, m, self.n,
+                                          self.wq.data_ptr(), self._stream())
+        if st != 0:
+            raise RuntimeError("tsqr_mi_apply_z_f32 -> %d %s" % (st, bq.last_error()))
+
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device="cuda")
 
@@ -63,18 +100,33 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
         return bq.error_invalid_matrix_size
     src, ld_src = a, lda
     for sweep in range(2 if reorthogonalize else 1):
-        r_loc = engine.empty(n, n)
-        engine.local_r(src, ld_src, m_local, r_loc)
-        if world > 1:
-            gathered = [engine.empty(n, n) for _ in range(world)]
-            dist.all_gather(gathered, r_loc, group=group)
-            # column-major (world*n) x n stack: an (n, world*n) row-major tensor whose row j is column j
-            stack = torch.cat(gathered, dim=1).contiguous()
-            r_new = engine.empty(n, n)
-            engine.local_r(stack, world * n, world * n, r_new)
-        else:
-            r_new = r_loc
-        engine.apply_rinv(q, ldq, src, ld_src, m_local, r_new)
+        r_new = None
+        if getattr(engine, "use_gram", False):
+            for level in (2, 1):                       # bf16-split Gram, then fp64 Gram; every rank takes the same decision
+                g = engine.gram(level, src, ld_src, m_local)
+                if world > 1:
+                    dist.all_reduce(g, group=group)
+                r_try = engine.empty(n, n)
+                if engine.chol(level, g, m_local, r_try) == 0:
+                    engine.apply_z(q, ldq, src, ld_src, m_local)
+                    r_new = r_try
+                    engine.last_engine = max(getattr(engine, "last_engine", 0), 3 if level == 2 else 1)
+                    break
+            if r_new is None:
+                engine.last_engine = 2
+        if r_new is None:                              # Householder TSQR engine
+            r_loc = engine.empty(n, n)
+            engine.local_r(src, ld_src, m_local, r_loc)
+            if world > 1:
+                gathered = [engine.empty(n, n) for _ in range(world)]
+                dist.all_gather(gathered, r_loc, group=group)
+                # column-major (world*n) x n stack: an (n, world*n) row-major tensor whose row j is column j
+                stack = torch.cat(gathered, dim=1).contiguous()
+                r_new = engine.empty(n, n)
+                engine.local_r(stack, world * n, world * n, r_new)
+            else:
+                r_new = r_loc
+            engine.apply_rinv(q, ldq, src, ld_src, m_local, r_new)
         if sweep == 0:
             r.copy_(r_new)
         else:
