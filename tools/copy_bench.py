@@ -20,3 +20,20 @@ q.copy_(a); t0.record()
 for _ in range(20): q.copy_(a)
 t1.record(); torch.cuda.synchronize()
 print('torch copy_: %.1f us' % (t0.elapsed_time(t1) / 20 * 1e3))
+
+# cold-cache read: evict the Infinity Cache (256 MiB) with a 1 GiB fill before every timed launch
+big = torch.empty(256 << 20, device='cuda')
+def cold(fn, reps=8):
+    tot = 0.0
+    for _ in range(reps):
+        big.fill_(1.0); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / reps * 1e3
+for mode in (0, 1):
+    for waves in (2048, 4096, 8192):
+        us = cold(lambda: L.tsqr_selftest_read_time(q.data_ptr(), a.data_ptr(), m, mode, waves, 1))
+        print('COLD READ mode %d waves %5d: %.1f us (2 launches incl. warm-up) ' % (mode, waves, us))
+us = cold(lambda: q.copy_(a)); print('COLD torch copy: %.1f us' % us)
+us = cold(lambda: a.sum()); print('COLD torch sum (read-only): %.1f us' % us)

@@ -147,6 +147,49 @@ __global__ __launch_bounds__(256) void read_cq_kernel(float* out, const float* a
 	}
 	if (acc == 123.456f) out[0] = acc;
 }
+// MODE 2: every wave instruction reads 1 KB contiguous of ONE column (lane l: rows 4l..4l+3); a workgroup covers a
+// 256-row x 64-column block, wave w takes columns w, w+4, ...
+__global__ __launch_bounds__(256) void read_linear_kernel(float* out, const float* a, size_t ld, size_t m, int nblocks_rows, int bpw) {
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	float acc = 0.f;
+	for (int b = blockIdx.x * bpw; b < min(nblocks_rows, (int)(blockIdx.x + 1) * bpw); b++) {
+		const size_t row0 = (size_t)b * 256;
+		tsqrmi::f32x4u v[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)(wv + 4 * k) * ld + row0 + 4 * lane);
+#pragma unroll
+		for (int k = 0; k < 16; k++) acc += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+	}
+	if (acc == 123.456f) out[0] = acc;
+}
+__global__ void flush_kernel(float* big, size_t n) {
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) big[i] = 1.0f;
+}
+// cold timing: evict caches with a 1 GiB fill, then time ONE launch
+extern "C" float tsqr_selftest_read_cold(float* q, const float* a, size_t m, int mode, int waves, float* big, size_t nbig, int reps) {
+	const int nch = (int)(m / 64);
+	const int cpw = (nch + waves - 1) / waves;
+	const int nwaves = (nch + cpw - 1) / cpw;
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	float tot = 0.f;
+	for (int it = 0; it < reps; it++) {
+		if (big) hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(256), 0, 0, big, nbig);
+		(void)hipEventRecord(e0, 0);
+		if (mode == 0) hipLaunchKernelGGL(read_cq_kernel<0>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
+		else if (mode == 1) hipLaunchKernelGGL(read_cq_kernel<1>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
+		else {
+			const int nb = (int)(m / 256); const int wgs = waves / 4; const int bpw = (nb + wgs - 1) / wgs;
+			hipLaunchKernelGGL(read_linear_kernel, dim3((nb + bpw - 1) / bpw), dim3(256), 0, 0, q, a, m, m, nb, bpw);
+		}
+		(void)hipEventRecord(e1, 0);
+		(void)hipEventSynchronize(e1);
+		float ms = 0.f;
+		(void)hipEventElapsedTime(&ms, e0, e1);
+		tot += ms;
+	}
+	return tot / reps;
+}
 extern "C" float tsqr_selftest_read_time(float* q, const float* a, size_t m, int mode, int waves, int reps) {
 	const int nch = (int)(m / 64);
 	const int cpw = (nch + waves - 1) / waves;

@@ -456,7 +456,11 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 #pragma unroll
 					for (int jp = 0; jp < 4; jp++) {
 						unsigned h, m, lo;
+#ifdef TSQR_ABL_NOSPLIT
+						h = __builtin_bit_cast(unsigned, p[t][8 * kt + 2 * jp]); m = __builtin_bit_cast(unsigned, p[t][8 * kt + 2 * jp + 1]); lo = h ^ m;
+#else
 						split3_pair(p[t][8 * kt + 2 * jp], p[t][8 * kt + 2 * jp + 1], h, m, lo);
+#endif
 						hh[jp] = h; mm[jp] = m; ll[jp] = lo;
 					}
 					oh[t] = __builtin_bit_cast(bf16x8, hh);
@@ -693,6 +697,87 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// Panel coupling for n > 64 (block modified Gram-Schmidt between 64-column panels; replaces the two cuBLAS GEMMs of
+// reference src/blockqr.cu:92-116):
+//   cross_kernel        : S = Qb^T Ap (64 x c) on v_mfma_f32_16x16x4_f32 -- exact fp32 FMA chains in both compute modes,
+//                         both operands straight from the (c,q) registers; per-workgroup partials like the Gram engine
+//   cross_finish_kernel : summed tiles -> S into R (ldr) and -S as a 64 x 64 column-major matrix for the update
+//   apply_kernel<E,4,true> : Ap <- Ap - Qb * S   (the apply kernel with a C input and a full, non-triangular Z)
+// ---------------------------------------------------------------------------------------------
+struct CrossArgs {
+	const float* x; size_t ldx; const float* y; size_t ldy; size_t m; int ny;     // X: m x 64, Y: m x ny
+	int nchunks; int cpw; int nwaves;
+	double* part;                        // [gridDim.x][16][256]
+};
+
+__global__ __launch_bounds__(256) void cross_kernel(const CrossArgs a) {
+	__shared__ float red[2][16 * 256];
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int gw = blockIdx.x * 4 + wv;
+	const int c = lane & 15, q = lane >> 4;
+	f32x4 acc[16];
+#pragma unroll
+	for (int t = 0; t < 16; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+	if (gw < a.nwaves) {
+		float px[4][16], py[4][16];
+		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
+		for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+			load_chunk<4>(px, a.x, a.ldx, (size_t)ch * 64, a.m, 64, c, q);
+			load_chunk<4>(py, a.y, a.ldy, (size_t)ch * 64, a.m, a.ny, c, q);
+#pragma unroll
+			for (int rho = 0; rho < 16; rho++)
+#pragma unroll
+				for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+					for (int tj = 0; tj < 4; tj++)
+						acc[4 * ti + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(px[ti][rho], py[tj][rho], acc[4 * ti + tj], 0, 0, 0);
+		}
+	}
+	if (wv >= 2) {
+#pragma unroll
+		for (int t = 0; t < 16; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[wv - 2][(t * 4 + r) * 64 + lane] = acc[t][r];
+	}
+	__syncthreads();
+	if (wv < 2) {
+#pragma unroll
+		for (int t = 0; t < 16; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) acc[t][r] += red[wv][(t * 4 + r) * 64 + lane];
+	}
+	__syncthreads();
+	if (wv == 1) {
+#pragma unroll
+		for (int t = 0; t < 16; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[0][(t * 4 + r) * 64 + lane] = acc[t][r];
+	}
+	__syncthreads();
+	if (wv == 0) {
+		double* out = a.part + (size_t)blockIdx.x * 16 * 256;
+#pragma unroll
+		for (int t = 0; t < 16; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = (double)(acc[t][r] + red[0][(t * 4 + r) * 64 + lane]);
+	}
+}
+
+// gsum: 16 tiles x 256 doubles in f32-MFMA accumulator order (tile 4*ti+tj, row = 4*(lane>>4)+reg, col = lane&15)
+__global__ __launch_bounds__(256) void cross_finish_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ zneg,
+                                                           const double* __restrict__ gsum, int ny) {
+	for (int e = blockIdx.x * 256 + threadIdx.x; e < 16 * 256; e += 256 * gridDim.x) {
+		const int t = e >> 8, reg = (e >> 6) & 3, l = e & 63;
+		const int i = 16 * (t >> 2) + 4 * (l >> 4) + reg;
+		const int j = 16 * (t & 3) + (l & 15);
+		const float v = (float)gsum[e];
+		zneg[(size_t)j * 64 + i] = (j < ny) ? -v : 0.0f;
+		if (j < ny) r[(size_t)j * ldr + i] = v;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // trinv_kernel: Z = inverse of the n x n upper-triangular R (fp64 arithmetic, fp32 in/out), written
 // zero-padded to NP x NP column-major (ld NP).  One wave; lane j solves R z = e_j by back substitution.
 // ---------------------------------------------------------------------------------------------
@@ -736,10 +821,13 @@ struct ApplyArgs {
 	const float* a; size_t lda; float* q; size_t ldq; size_t m; int n;
 	const float* z;                     // NP x NP, ld NP
 	int nchunks; int cpw; int nwaves;
+	int n_out;                          // UPD only: columns of the output / C input (n is then the contraction length, 64)
 };
 
-template <int ENGINE, int NT>
+template <int ENGINE, int NT, bool UPD = false>
 __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
+	// UPD = false: Q = A * Z with Z upper triangular (zero blocks skipped).  UPD = true: Q <- Q + A * Z with a full Z
+	// (the panel update Ap <- Ap - Qb * S: Z = -S, the C input is read from and written back to q).
 	constexpr int NP = 16 * NT;
 	constexpr int AS = 20;                               // column stride (floats) of the per-wave 16-row A slab
 	constexpr int ZS = NP + 16;                          // row stride of the fp32 Z image
@@ -801,7 +889,20 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 			__builtin_amdgcn_wave_barrier();
 			f32x4 acc[NT];
 #pragma unroll
-			for (int ct = 0; ct < NT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+			for (int ct = 0; ct < NT; ct++) {
+				acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+				if constexpr (UPD) {
+					const int col = 16 * ct + c;
+					if (col < a.n_out) {
+						const float* src = a.q + (size_t)col * a.ldq + row0 + 16 * rt + 4 * q;
+						if (full) acc[ct] = *reinterpret_cast<const f32x4u*>(src);
+						else {
+#pragma unroll
+							for (int i = 0; i < 4; i++) acc[ct][i] = (row0 + 16 * rt + 4 * q + i < a.m) ? src[i] : 0.0f;
+						}
+					}
+				}
+			}
 			if constexpr (ENGINE == 0) {
 				const float* Zs = reinterpret_cast<const float*>(zbase);
 #pragma unroll
@@ -810,7 +911,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 					const float av = At[k * AS + c];
 #pragma unroll
 					for (int ct = 0; ct < NT; ct++) {
-						if (4 * t <= 16 * ct + 15) {          // Z[k][j] = 0 for k > j
+						if (UPD || 4 * t <= 16 * ct + 15) {   // triangular Z: Z[k][j] = 0 for k > j
 							const float bv = Zs[k * ZS + 16 * ct + c];
 							acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ct], 0, 0, 0);
 						}
@@ -877,13 +978,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 					pair(I0{}, I0{}, I0{}, I1{});
 					pair(I0{}, I2{}, I0{}, I3{});
 					pair(I1{}, I2{}, I1{}, I3{});
+					if constexpr (UPD) pair(I1{}, I0{}, I1{}, I1{});      // full Z: the blocks a triangular Z leaves out
 				}
 			}
 			// D layout: col = lane&15, rows 4*(lane>>4) + i of this 16-row tile
 #pragma unroll
 			for (int ct = 0; ct < NT; ct++) {
 				const int col = 16 * ct + c;
-				if (col < a.n) {
+				if (col < (UPD ? a.n_out : a.n)) {
 					float* dst = a.q + (size_t)col * a.ldq + row0 + 16 * rt + 4 * q;
 					if (full) {
 						*reinterpret_cast<f32x4u*>(dst) = acc[ct];
@@ -896,86 +998,6 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 			}
 		}
 	}
-}
-
-// ---------------------------------------------------------------------------------------------
-// panel coupling for n > 64 (block modified Gram-Schmidt between 64-column panels), fp32 FMA.
-//   proj_partial_kernel : S_part[slab] = Qb[slab rows]^T * Ap[slab rows]      (pb x pc, pb,pc <= 64)
-//   proj_reduce_kernel  : S = sum over slabs (fixed order -> deterministic); also written into R
-//   update_kernel       : Ap -= Qb * S
-// replaces the two cuBLAS GEMMs of reference src/blockqr.cu:92-116.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void proj_partial_kernel(float* __restrict__ part, const float* __restrict__ qb, size_t ldq,
-                                                           const float* __restrict__ ap, size_t lda, size_t m,
-                                                           int pb, int pc, size_t rows_per_slab) {
-	__shared__ float Qs[64][65];
-	__shared__ float As[64][65];
-	const int tid = threadIdx.x;
-	const int ti = tid & 15, tj = tid >> 4;              // thread owns S[4*ti..+3][4*tj..+3]
-	float acc[4][4];
-#pragma unroll
-	for (int i = 0; i < 4; i++)
-#pragma unroll
-		for (int j = 0; j < 4; j++) acc[i][j] = 0.0f;
-	const size_t r_begin = (size_t)blockIdx.x * rows_per_slab;
-	const size_t r_end = min(m, r_begin + rows_per_slab);
-	for (size_t r0 = r_begin; r0 < r_end; r0 += 64) {
-		for (int idx = tid; idx < 64 * 64; idx += 256) {
-			const int rr = idx & 63, cc = idx >> 6;
-			const size_t row = r0 + rr;
-			const bool ok = row < r_end;
-			Qs[cc][rr] = (ok && cc < pb) ? qb[(size_t)cc * ldq + row] : 0.0f;
-			As[cc][rr] = (ok && cc < pc) ? ap[(size_t)cc * lda + row] : 0.0f;
-		}
-		__syncthreads();
-#pragma unroll 4
-		for (int rr = 0; rr < 64; rr++) {
-			float qv[4], av[4];
-#pragma unroll
-			for (int i = 0; i < 4; i++) { qv[i] = Qs[4 * ti + i][rr]; av[i] = As[4 * tj + i][rr]; }
-#pragma unroll
-			for (int i = 0; i < 4; i++)
-#pragma unroll
-				for (int j = 0; j < 4; j++) acc[i][j] = fmaf(qv[i], av[j], acc[i][j]);
-		}
-		__syncthreads();
-	}
-	float* out = part + (size_t)blockIdx.x * 4096;
-#pragma unroll
-	for (int i = 0; i < 4; i++)
-#pragma unroll
-		for (int j = 0; j < 4; j++) out[(4 * tj + j) * 64 + 4 * ti + i] = acc[i][j];   // [col j][row i]
-}
-
-__global__ __launch_bounds__(256) void proj_reduce_kernel(float* __restrict__ s, float* __restrict__ r, size_t ldr,
-                                                          const float* __restrict__ part, int nslab, int pb, int pc) {
-	for (int idx = threadIdx.x + blockIdx.x * 256; idx < 4096; idx += 256 * gridDim.x) {
-		float acc = 0.0f;
-		for (int t = 0; t < nslab; t++) acc += part[(size_t)t * 4096 + idx];
-		s[idx] = acc;
-		const int i = idx & 63, j = idx >> 6;
-		if (i < pb && j < pc) r[(size_t)j * ldr + i] = acc;
-	}
-}
-
-__global__ __launch_bounds__(256) void update_kernel(float* __restrict__ ap, size_t lda, const float* __restrict__ qb, size_t ldq,
-                                                     const float* __restrict__ s, size_t m, int pb, int pc) {
-	__shared__ float Ss[64 * 64];                        // Ss[j*64 + i] = S[i][j]
-	for (int idx = threadIdx.x; idx < 4096; idx += 256) Ss[idx] = s[idx];
-	__syncthreads();
-	const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (row >= m) return;
-	float acc[64];
-#pragma unroll
-	for (int j = 0; j < 64; j++) acc[j] = 0.0f;
-	for (int i = 0; i < pb; i++) {
-		const float qv = qb[(size_t)i * ldq + row];
-#pragma unroll
-		for (int j = 0; j < 64; j++) acc[j] = fmaf(qv, Ss[j * 64 + i], acc[j]);
-	}
-#pragma unroll
-	for (int j = 0; j < 64; j++)
-		if (j < pc) ap[(size_t)j * lda + row] -= acc[j];
 }
 
 // R <- R2 * R1 (n x n upper triangular, fp64 accumulation).  r1 is a packed copy (ld n) of the old R.

@@ -70,7 +70,6 @@ void prof_collect() {              // after the stream is idle
 }
 
 constexpr size_t PW = 64;          // panel width
-constexpr int NSLAB = 512;         // row slabs of the projection kernel
 
 inline int fail(hipError_t e, const char* what) {
 	g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -148,11 +147,11 @@ WqLayout wq_layout(size_t m, size_t n) {
 	o = (o + 63) & ~(size_t)63;
 	L.z = o; o += 4096;
 	L.s = o; o += 4096;
-	L.part = o; o += (n > PW ? (size_t)NSLAB * 4096 : 0);
+	L.part = o;                                          // (unused since the MFMA coupling kernels)
 	L.r1 = o; o += n * n;
 	L.r2 = o; o += n * n;
 	o = (o + 63) & ~(size_t)63;
-	L.gsub = o; o += (size_t)(GRAM_NSPLIT + 1) * 10 * 256 * 2;
+	L.gsub = o; o += (size_t)(GRAM_NSPLIT + 1) * 16 * 256 * 2;    // sub-sums + summed tiles (Gram: 10 tiles, coupling: 16)
 	L.status = o; o += 64;
 	L.total = o;
 	return L;
@@ -252,23 +251,23 @@ int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t n
 // Gram engine: R (n x n, ldr) and Z = inverse(R) (NP x NP in z_buf) of src (m x n); status -> wq[L.status]
 int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size_t m, size_t n,
            float* wq, float* wr, const WqLayout& L, bool bf16, hipStream_t st) {
-	double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 10 * 256;
+	double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 16 * 256;
 	const int rc = gram_g(gsum, src, ld, m, n, wq, wr, L, bf16, st);
 	if (rc) return rc;
 	return chol_from_g(r, ldr, z_buf, gsum, n, wq, L, bf16, st);
 }
 
-template <int E, int NT> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
+template <int E, int NT, bool UPD = false> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
 	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
 	const size_t lds = sizeof(float) * 4 * NP * 20 + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)3 * KT * NT * 512 * 2);
 	static bool attr_done = false;
 	if (!attr_done) {
-		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_kernel<E, NT>),
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_kernel<E, NT, UPD>),
 		                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		attr_done = true;
 	}
 	const int blocks = (a.nwaves + 3) / 4;
-	hipLaunchKernelGGL((tsqrmi::apply_kernel<E, NT>), dim3(blocks), dim3(256), lds, st, a);
+	hipLaunchKernelGGL((tsqrmi::apply_kernel<E, NT, UPD>), dim3(blocks), dim3(256), lds, st, a);
 	return 0;
 }
 template <int E> int dispatch_apply_nt(int NT, const tsqrmi::ApplyArgs& a, hipStream_t st) {
@@ -361,15 +360,30 @@ int sweep(int engine, int r_engine, bool check_now, float* q, size_t ldq, float*
 		float* ap = a + P * lda;
 		for (size_t bi = 0; bi < pi; bi++) {             // block modified Gram-Schmidt against finished panels
 			const size_t B = bi * PW;
-			const size_t rows_per_slab = 64 * std::max<size_t>(1, cdiv(cdiv(m, 64), NSLAB));
-			const int nslab = (int)cdiv(m, rows_per_slab);
 			ProfScope ps(KC_COUPLE, st);
-			hipLaunchKernelGGL(tsqrmi::proj_partial_kernel, dim3(nslab), dim3(256), 0, st,
-			                   wq + L.part, q + B * ldq, ldq, ap, lda, m, (int)PW, (int)c, rows_per_slab);
-			hipLaunchKernelGGL(tsqrmi::proj_reduce_kernel, dim3(16), dim3(256), 0, st,
-			                   wq + L.s, r + P * ldr + B, ldr, wq + L.part, nslab, (int)PW, (int)c);
-			hipLaunchKernelGGL(tsqrmi::update_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st,
-			                   ap, lda, q + B * ldq, ldq, wq + L.s, m, (int)PW, (int)c);
+			// S = Qb^T Ap  (exact fp32 MFMA), written into R(B:B+64, P:P+c); then Ap <- Ap - Qb * S on the mode's MFMA engine
+			const GramPlan g = gram_plan(m, PW);
+			tsqrmi::CrossArgs ca{};
+			ca.x = q + B * ldq; ca.ldx = ldq; ca.y = ap; ca.ldy = lda; ca.m = m; ca.ny = (int)c;
+			ca.nchunks = g.nch; ca.cpw = g.cpw; ca.nwaves = g.nwaves; ca.part = reinterpret_cast<double*>(wr);
+			hipLaunchKernelGGL(tsqrmi::cross_kernel, dim3(g.nblocks), dim3(256), 0, st, ca);
+			const int nelem = 16 * 256;
+			const int nsplit = std::min(GRAM_NSPLIT, g.nblocks);
+			double* sub = reinterpret_cast<double*>(wq + L.gsub);
+			double* gsum = sub + (size_t)GRAM_NSPLIT * nelem;
+			hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
+			                   sub, ca.part, g.nblocks, nelem, nsplit);
+			hipLaunchKernelGGL(tsqrmi::gram_reduce2_kernel, dim3((nelem + 255) / 256), dim3(256), 0, st, gsum, sub, nelem, nsplit);
+			hipLaunchKernelGGL(tsqrmi::cross_finish_kernel, dim3(16), dim3(256), 0, st, r + P * ldr + B, ldr, wq + L.s, gsum, (int)c);
+			HIPCHK(hipGetLastError());
+			tsqrmi::ApplyArgs ua{};
+			ua.a = q + B * ldq; ua.lda = ldq; ua.q = ap; ua.ldq = lda; ua.m = m; ua.n = (int)PW; ua.z = wq + L.s; ua.n_out = (int)c;
+			const size_t nch = cdiv(m, 64);
+			ua.cpw = (int)std::max<size_t>(1, cdiv(nch, (size_t)g_apply_waves));
+			ua.nchunks = (int)nch;
+			ua.nwaves = (int)cdiv(nch, (size_t)ua.cpw);
+			const int rc2 = (engine == 0) ? launch_apply<0, 4, true>(ua, st) : launch_apply<1, 4, true>(ua, st);
+			if (rc2) return rc2;
 			HIPCHK(hipGetLastError());
 		}
 		const int rc = panel_qr(engine, r_engine, check_now, q + P * ldq, ldq, r + P * ldr + P, ldr, ap, lda, m, c, wq, wr, L, h_pinned, st);
@@ -398,6 +412,7 @@ size_t tsqr_mi_working_r_size(size_t m, size_t n) {
 	for (size_t P = 0; P < n; P += PW) {
 		need = std::max(need, make_plan(m, std::min(PW, n - P)).stack_a);
 		need = std::max(need, gram_plan(m, std::min(PW, n - P)).part_floats);
+		if (n > PW) need = std::max(need, (size_t)gram_plan(m, PW).nblocks * 16 * 256 * 2);
 	}
 	// the stack of a dist/gathered fold is tiny; nothing extra needed
 	return std::max(ref_wr(m, n), need);
@@ -596,7 +611,7 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 		int rc;
 		if (use_gram && allreduce) {
 			// Gram engine: local Gram tiles -> all-reduce (fp64 sum) -> Cholesky on every rank -> apply; rejected levels step down
-			double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 10 * 256;
+			double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 16 * 256;
 			const size_t gelems = (np_of(n) / 16) * (np_of(n) / 16 + 1) / 2 * 256;
 			bool done = false;
 			for (int level = g_gram_level; level >= 1 && !done; level--) {
