@@ -99,6 +99,8 @@ struct FoldArgs {
 	const float* src; size_t ld; size_t m; int n;     // source matrix (m x n, column-major)
 	int nchunks; int cpw; int nwaves;                 // chunk = 64 rows; wave w folds chunks [w*cpw, (w+1)*cpw)
 	float* dst; size_t dst_ld; int rows_store; int cols_store;   // wave w writes rows [w*rows_store, ...) of dst
+	int tri_init;                                     // tree levels over 64-row upper-triangular blocks: the wave's first block IS its
+	                                                  // initial R (copied, not folded), which makes a binary tree cost one fold per level
 };
 
 // acc += (lane 16q+K of src) * other     -- one v_fmac_f32_dpp.  FIRST=true pads the two wait states a
@@ -126,11 +128,17 @@ __device__ __forceinline__ float fast_rcp(float a) {     // v_rcp_f32 + one Newt
 // The reflector is kept orthogonal to rounding whatever the accuracy of v_sqrt/v_rcp: beta only fixes v = [1; x*inv],
 // tau is then computed from that v (tau = 2 / (1 + inv^2 ||x||^2)) and the pivot entry is updated like any other
 // column (r_kk - tau*w_k), so an inexact beta shows up as a tiny backward error, never as loss of orthogonality.
-template <int KK>
+//   glim : last 4-register group (16-row tile) of the chunk that carries data in this panel (3 for a dense chunk; the panel
+//          index when the chunk is an upper-triangular R block: rows below the panel's own row tile are zero)
+template <int KK, bool TRI>
 __device__ __forceinline__ void panel_step(float (&p0)[16], float (&Trow)[16], float& sc, float* __restrict__ Rrow, int c,
-                                           float rkk, float rkc) {
+                                           float rkk, float rkc, int glim) {
 	float acc = 0.0f;
-	static_for<0, 16>([&](auto r) { fmac_bcast<KK, decltype(r)::value == 0>(acc, p0[decltype(r)::value], p0[decltype(r)::value]); });
+	static_for<0, 4>([&](auto g) {
+		constexpr int G = decltype(g)::value;
+		if (!TRI || G <= glim)                           // wave-uniform; compiled out for dense chunks
+			static_for<0, 4>([&](auto r) { fmac_bcast<KK, (TRI ? decltype(r)::value == 0 : 4 * G + decltype(r)::value == 0)>(acc, p0[4 * G + decltype(r)::value], p0[4 * G + decltype(r)::value]); });
+	});
 	const float d = xq_sum(acc);                         // x_k^T x_c for every column c of the tile
 	const float ss = bcast16<KK>(d);                     // ||x_k||^2
 	const float nrm = __builtin_amdgcn_sqrtf(fmaf(rkk, rkk, ss));
@@ -143,7 +151,11 @@ __device__ __forceinline__ void panel_step(float (&p0)[16], float (&Trow)[16], f
 	const bool act = c > KK;
 	const float g = act ? -tw * inv : 0.0f;              // b_c -= tau*w*v_k  ==  b_c += x_k * g
 	if (c >= KK) Rrow[c - KK] = rkc - tw;                // predicated: lanes c < KK hold a stale prefetch of a finished entry
-	static_for<0, 16>([&](auto r) { fmac_bcast<KK, false>(p0[decltype(r)::value], p0[decltype(r)::value], g); });
+	static_for<0, 4>([&](auto gg) {
+		constexpr int G = decltype(gg)::value;
+		if (!TRI || G <= glim)
+			static_for<0, 4>([&](auto r) { fmac_bcast<KK, (TRI && decltype(r)::value == 0)>(p0[4 * G + decltype(r)::value], p0[4 * G + decltype(r)::value], g); });
+	});
 	// T(0:KK, KK) = -tau * T(0:KK, 0:KK) * (V(:, 0:KK)^T v_k);   lane c owns row c of T
 	if constexpr (KK > 0) {
 		const float z = (c < KK) ? d * sc * inv : 0.0f;
@@ -159,8 +171,9 @@ __device__ __forceinline__ void panel_step(float (&p0)[16], float (&Trow)[16], f
 // block reflector of the finished panel applied to one trailing tile (all operands in registers / LDS rows of R)
 //   pj: trailing tile;  v: V of the panel in (c,q) layout (scaled);  vt[rt]: -V^T pieces (lane <-> row in tile rt)
 //   ta[r] = T[4q+r][c];  Rp: packed R in LDS;  K0: first column of the panel;  colj: first column of the trailing tile
+template <bool TRI>
 __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[16], const f32x4 (&vt)[4], const float (&ta)[4],
-                                             float* __restrict__ Rp, int K0, int colj, int NP, int c, int q) {
+                                             float* __restrict__ Rp, int K0, int colj, int NP, int c, int q, int glim) {
 	// W0 = rows K0..K0+15 of R restricted to this tile, D layout (row 4q+r, column c)
 	int idx[4];
 	f32x4 w0;
@@ -172,7 +185,11 @@ __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[1
 	}
 	f32x4 w = w0;                                        // W = W0 + V^T B
 #pragma unroll
-	for (int rho = 0; rho < 16; rho++) w = __builtin_amdgcn_mfma_f32_16x16x4f32(v[rho], pj[rho], w, 0, 0, 0);
+	for (int rt = 0; rt < 4; rt++)
+		if (!TRI || rt <= glim) {                        // V is zero in the row tiles below the panel of a triangular block
+#pragma unroll
+			for (int r = 0; r < 4; r++) w = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * rt + r], pj[4 * rt + r], w, 0, 0, 0);
+		}
 	f32x4 wp = {0.f, 0.f, 0.f, 0.f};                     // W' = T^T W   (k-slot (q, r) <-> panel column 4q+r)
 #pragma unroll
 	for (int r = 0; r < 4; r++) wp = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[r], w[r], wp, 0, 0, 0);
@@ -180,6 +197,7 @@ __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[1
 	for (int r = 0; r < 4; r++) Rp[idx[r]] = w0[r] - wp[r];
 #pragma unroll
 	for (int rt = 0; rt < 4; rt++) {                     // B -= V W'
+		if (TRI && rt > glim) continue;
 		f32x4 acc = {pj[4 * rt], pj[4 * rt + 1], pj[4 * rt + 2], pj[4 * rt + 3]};
 #pragma unroll
 		for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[rt][r], wp[r], acc, 0, 0, 0);
@@ -190,7 +208,9 @@ __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[1
 #ifndef TSQR_FOLD_WAVES_PER_SIMD
 #define TSQR_FOLD_WAVES_PER_SIMD 2
 #endif
-template <int NT>
+// TRI: the folded blocks are 64-row upper-triangular R factors (tree levels with NT == 4): the wave's first block is copied
+// into R instead of folded and every panel skips the row tiles that are structurally zero.
+template <int NT, bool TRI = false>
 __global__ __launch_bounds__(256, TSQR_FOLD_WAVES_PER_SIMD) void fold_kernel(const FoldArgs a) {
 	constexpr int NP = 16 * NT;
 	constexpr int RP = (NP * (NP + 1)) / 2 + 16;         // packed upper triangle (+ slack for masked reads)
@@ -208,11 +228,27 @@ __global__ __launch_bounds__(256, TSQR_FOLD_WAVES_PER_SIMD) void fold_kernel(con
 
 	float p[NT][16];
 	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
-	for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+	int ch_first = gw * a.cpw;
+	if (TRI && ch_first < ch_end) {
+		// the first block is the initial R: load it like any chunk (16 wide loads in flight) and scatter its upper triangle
+		// into the packed rows -- register (ct, 4rt+i) of lane (c,q) is entry (row 16rt+4q+i, column 16ct+c)
+		load_chunk<NT>(p, a.src, a.ld, (size_t)ch_first * 64, a.m, a.n, c, q);
+#pragma unroll
+		for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+			for (int rho = 0; rho < 16; rho++) {
+				const int row = 16 * (rho >> 2) + 4 * q + (rho & 3), col = 16 * ct + c;
+				if (col >= row) Rw[row * NP - (row * (row - 1)) / 2 + col - row] = p[ct][rho];
+			}
+		ch_first++;
+		__builtin_amdgcn_wave_barrier();
+	}
+	for (int ch = ch_first; ch < ch_end; ch++) {
 		load_chunk<NT>(p, a.src, a.ld, (size_t)ch * 64, a.m, a.n, c, q);
 #pragma unroll 1
 		for (int S = 0; S < ntile; S++) {
 			const int K0 = 16 * S;
+			const int glim = TRI ? S : 3;                // triangular source block: panel S is zero below row tile S
 			float Trow[16];
 #pragma unroll
 			for (int l = 0; l < 16; l++) Trow[l] = 0.0f;
@@ -224,7 +260,7 @@ __global__ __launch_bounds__(256, TSQR_FOLD_WAVES_PER_SIMD) void fold_kernel(con
 				const int offN = offK + NP - (K0 + KK);  // row K+1
 				float rkk_n = 0.0f, rkc_n = 0.0f;
 				if (KK < 15) { rkk_n = Rw[offN]; rkc_n = Rw[offN + c - (KK + 1)]; }   // not touched by step KK
-				if (K0 + KK < a.n) panel_step<KK>(p[0], Trow, sc, Rw + offK, c, rkk, rkc);
+				if (K0 + KK < a.n) panel_step<KK, TRI>(p[0], Trow, sc, Rw + offK, c, rkk, rkc, glim);
 				offK = offN; rkk = rkk_n; rkc = rkc_n;
 			});
 			const int ntrail = ntile - 1 - S;
@@ -246,14 +282,16 @@ __global__ __launch_bounds__(256, TSQR_FOLD_WAVES_PER_SIMD) void fold_kernel(con
 #pragma unroll
 				for (int rt = 0; rt < 4; rt++) {
 					f32x4 t = {0.f, 0.f, 0.f, 0.f};
+					if (!TRI || rt <= glim) {
 #pragma unroll
-					for (int r = 0; r < 4; r++)
-						t = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][4 * rt + r], (c == 4 * q + r) ? -1.0f : 0.0f, t, 0, 0, 0);
+						for (int r = 0; r < 4; r++)
+							t = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][4 * rt + r], (c == 4 * q + r) ? -1.0f : 0.0f, t, 0, 0, 0);
+					}
 					vt[rt] = t;
 				}
 				static_for<1, NT>([&](auto jj) {
 					constexpr int J = decltype(jj)::value;
-					if (J <= ntrail) trail_update(p[J], p[0], vt, ta, Rw, K0, K0 + 16 * J, NP, c, q);
+					if (J <= ntrail) trail_update<TRI>(p[J], p[0], vt, ta, Rw, K0, K0 + 16 * J, NP, c, q, glim);
 				});
 				__builtin_amdgcn_wave_barrier();
 			}
@@ -265,13 +303,20 @@ __global__ __launch_bounds__(256, TSQR_FOLD_WAVES_PER_SIMD) void fold_kernel(con
 			});
 		}
 	}
-	// write R: lane <-> row, loop over columns (consecutive lanes -> consecutive addresses)
+	// write R: lane <-> row, four columns per iteration so the LDS reads overlap (consecutive lanes -> consecutive addresses)
 	float* dst = a.dst + (size_t)gw * a.rows_store;
 	if (lane < a.rows_store) {
 		const int off = lane * NP - (lane * (lane - 1)) / 2;
-		for (int col = 0; col < a.cols_store; col++) {
-			const float v = (lane <= col && lane < NP && col < NP) ? Rw[off + col - lane] : 0.0f;
-			dst[(size_t)col * a.dst_ld + lane] = v;
+		for (int col0 = 0; col0 < a.cols_store; col0 += 4) {
+			float v[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int col = col0 + u;
+				v[u] = (lane <= col && lane < NP && col < NP) ? Rw[off + col - lane] : 0.0f;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (col0 + u < a.cols_store) dst[(size_t)(col0 + u) * a.dst_ld + lane] = v[u];
 		}
 	}
 }
@@ -778,35 +823,62 @@ __global__ __launch_bounds__(256) void cross_finish_kernel(float* __restrict__ r
 }
 
 // ---------------------------------------------------------------------------------------------
-// trinv_kernel: Z = inverse of the n x n upper-triangular R (fp64 arithmetic, fp32 in/out), written
-// zero-padded to NP x NP column-major (ld NP).  One wave; lane j solves R z = e_j by back substitution.
+// trinv_kernel: Z = inverse of the n x n upper-triangular R (fp64 arithmetic, fp32 in/out), written zero-padded to
+// NP x NP column-major (ld NP).  Forward elimination of [R^T | I] with the rows interleaved over the four waves in
+// registers (same scheme as chol_kernel: M = R^-T, Z = M^T), one barrier per step.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void trinv_kernel(float* __restrict__ z, const float* __restrict__ r, size_t ldr,
-                                                   int n, int NP) {
-	__shared__ float Rl[64 * 65];
-	const int j = threadIdx.x;
-	for (int col = 0; col < n; col++)
-		Rl[col * 65 + j] = (j < n) ? r[(size_t)col * ldr + j] : 0.0f;   // Rl[col][row]
+template <int U>
+__device__ __forceinline__ void trinv_step(double (&mm)[16], double* Mrow, const double* Rs, const double* rdiag,
+                                           float* __restrict__ z, int w, int j, int n, int NP, int kk) {
+	const int K = 4 * kk + U;
+	if (K >= n) return;                                  // uniform over the workgroup
+	double* mr = Mrow + (U & 1) * 64;
+	if (w == U) {
+		const double mk = mm[0] * rdiag[K];
+		mr[j] = mk;
+		if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mk : 0.0f;     // Z[j][K] = M[K][j]
+	}
 	__syncthreads();
-	double zc[64];
+	const double mkc = mr[j];
+	const int nlive = 16 - kk;
 #pragma unroll
-	for (int i = 0; i < 64; i++) zc[i] = 0.0;
-	if (j < n) {
+	for (int gq = 0; gq < 4; gq++) {
+		if (4 * gq < nlive) {
+			double rki[4];
 #pragma unroll
-		for (int i = 63; i >= 0; i--) {
-			if (i <= j && i < n) {                      // runtime mask, static register index
-				double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-				for (int k = i + 1; k < 64; k++)
-					if (k <= j) s -= (double)Rl[k * 65 + i] * zc[k];
-				zc[i] = s / (double)Rl[i * 65 + i];
+			for (int u = 0; u < 4; u++) {
+				const int i = w + 4 * (kk + 4 * gq + u);
+				const double v = Rs[K * 65 + min(i, 63)];            // R[K][i]
+				rki[u] = (i > K && i < 64) ? v : 0.0;
 			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) mm[4 * gq + u] = fma(-rki[u], mkc, mm[4 * gq + u]);
 		}
 	}
-	if (j < NP) {
+}
+
+__global__ __launch_bounds__(256) void trinv_kernel(float* __restrict__ z, const float* __restrict__ r, size_t ldr,
+                                                    int n, int NP) {
+	__shared__ double Rs[64 * 65];               // Rs[row * 65 + col]
+	__shared__ double Mrow[2 * 64], rdiag[64];
+	const int t = threadIdx.x;
+	const int j = t & 63, w = t >> 6;
+	for (int e = t; e < 64 * 64; e += 256) {
+		const int row = e & 63, col = e >> 6;
+		Rs[row * 65 + col] = (row <= col && col < n) ? (double)r[(size_t)col * ldr + row] : 0.0;
+	}
+	for (int e = n * NP + t; e < NP * NP; e += 256) z[e] = 0.0f;          // padding rows of Z
+	__syncthreads();
+	if (t < 64) rdiag[t] = (t < n) ? 1.0 / Rs[t * 65 + t] : 0.0;
+	double mm[16];
 #pragma unroll
-		for (int i = 0; i < 64; i++)
-			if (i < NP) z[(size_t)j * NP + i] = (float)zc[i];
+	for (int s = 0; s < 16; s++) mm[s] = (w + 4 * s == j) ? 1.0 : 0.0;
+	__syncthreads();
+#pragma unroll 1
+	for (int kk = 0; kk < 16; kk++) {
+		static_for<0, 4>([&](auto u) { trinv_step<decltype(u)::value>(mm, Mrow, Rs, rdiag, z, w, j, n, NP, kk); });
+#pragma unroll
+		for (int s = 0; s < 15; s++) mm[s] = mm[s + 1];
 	}
 }
 

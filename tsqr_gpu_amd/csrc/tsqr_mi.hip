@@ -108,7 +108,9 @@ Plan make_plan(size_t m, size_t n) {
 	const size_t cpw_min = std::max<size_t>(1, cdiv(2 * p.NP, 64));
 	for (;;) {
 		const size_t nch = cdiv(rows, 64);
-		size_t cpw = (lv == 0) ? std::max(cpw_min, cdiv(nch, (size_t)g_level0_waves)) : std::max(cpw_min, (size_t)g_tree_cpw);
+		// tree levels over 64-row triangular blocks are binary: the first block is copied into R (FoldArgs::tri_init), one fold per level
+		size_t cpw = (lv == 0) ? std::max(cpw_min, cdiv(nch, (size_t)g_level0_waves))
+		                       : (p.NP == 64 ? (size_t)2 : std::max(cpw_min, (size_t)g_tree_cpw));
 		size_t nw = cdiv(nch, cpw);
 		if (nw <= 1 || nw * p.NP >= rows) { nw = 1; cpw = nch; }
 		p.rows[lv] = rows; p.nch[lv] = (int)nch; p.cpw[lv] = (int)cpw; p.nw[lv] = (int)nw;
@@ -159,7 +161,10 @@ WqLayout wq_layout(size_t m, size_t n) {
 
 template <int NT> int launch_fold(const tsqrmi::FoldArgs& a, hipStream_t st) {
 	const int blocks = (a.nwaves + 3) / 4;
-	hipLaunchKernelGGL(tsqrmi::fold_kernel<NT>, dim3(blocks), dim3(256), 0, st, a);
+	if constexpr (NT == 4) {
+		if (a.tri_init) { hipLaunchKernelGGL((tsqrmi::fold_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a); return 0; }
+	}
+	hipLaunchKernelGGL((tsqrmi::fold_kernel<NT, false>), dim3(blocks), dim3(256), 0, st, a);
 	return 0;
 }
 int dispatch_fold(int NT, const tsqrmi::FoldArgs& a, hipStream_t st) {
@@ -182,6 +187,7 @@ int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n
 		a.src = cur; a.ld = cur_ld; a.m = p.rows[lv];
 		a.n = (int)n;                                    // stacks are NP wide, only the first n columns carry data
 		a.nchunks = p.nch[lv]; a.cpw = p.cpw[lv]; a.nwaves = p.nw[lv];
+		a.tri_init = (lv > 0 && p.NP == 64) ? 1 : 0;
 		if (p.nw[lv] == 1) {
 			a.dst = r; a.dst_ld = ldr; a.rows_store = (int)n; a.cols_store = (int)n;
 		} else {
@@ -286,7 +292,7 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
 	const int NT = (int)(NP / 16);
 	if (!z_ready) {
 		ProfScope ps(KC_TRINV, st);
-		hipLaunchKernelGGL(tsqrmi::trinv_kernel, dim3(1), dim3(64), 0, st, z_buf, r, ldr, (int)n, (int)NP);
+		hipLaunchKernelGGL(tsqrmi::trinv_kernel, dim3(1), dim3(256), 0, st, z_buf, r, ldr, (int)n, (int)NP);
 	}
 	HIPCHK(hipGetLastError());
 	tsqrmi::ApplyArgs aa{};
