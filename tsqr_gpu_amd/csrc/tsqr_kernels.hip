@@ -615,50 +615,62 @@ __global__ __launch_bounds__(256) void gram_reduce2_kernel(double* __restrict__ 
 	          (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
 }
 
-// one elimination step; U = K & 3 is the wave that owns row K; after the rotation of the previous groups row K sits in
-// g[0] / mm[0] of that wave (g[s] <-> row w + 4 (kk + s)).  Nothing on the pivot path reads memory.
+// Row ownership of the elimination kernels: thread (w, j) holds column j of the rows  row(w, s) = 16*(s>>2) + 4*w + (s&3),
+// i.e. every wave owns FOUR consecutive rows of each 16-row block.  A "group" = those four rows: its owner factors them
+// against each other in registers (lane broadcasts, no LDS), publishes the four finished rows, and after ONE barrier all
+// waves apply the four rank-1 updates to their remaining rows.  16 barriers for 64 rows; after the four groups of a block
+// the register rows rotate by four so the active block is always slots 0..3.
 template <int U>
-__device__ __forceinline__ void chol_step(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* __restrict__ z,
-                                          double* pv, int w, int j, int n, int NP, int kk) {
-	const int K = 4 * kk + U;
-	if (K >= n) return;                                  // uniform over the workgroup (the barrier below included)
-	double* rr = Rrow + (U & 1) * 64;
-	double* mr = Mrow + (U & 1) * 64;
+__device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* __restrict__ z,
+                                           double* pv, int w, int j, int n, int NP, int kk) {
+	const int K0 = 16 * kk + 4 * U;
+	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
+	double* rr = Rrow + (U & 1) * 256;                   // [4][64]
+	double* mr = Mrow + (U & 1) * 256;
 	if (w == U) {
-		const double piv0 = bcast_lane_f64(g[0], K);
-		const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; the breakdown is flagged from pv[] afterwards
-		double y = __builtin_amdgcn_rsq(piv);
-		y = y * (1.5 - 0.5 * piv * y * y);
-		y = y * (1.5 - 0.5 * piv * y * y);
-		const double rk = (j > K) ? g[0] * y : ((j == K) ? piv * y : 0.0);
-		const double mk = mm[0] * y;
-		rr[j] = rk;
-		mr[j] = mk;
-		Rf[K * 65 + j] = (float)rk;
-		if (j == 0) pv[K] = piv0;
-		if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mk : 0.0f;     // Z[j][K] = M[K][j]
+		static_for<0, 4>([&](auto uu) {
+			constexpr int u = decltype(uu)::value;
+			const int K = K0 + u;
+			const double piv0 = bcast_lane_f64(g[u], K);
+			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
+			double y = __builtin_amdgcn_rsq(piv);
+			y = y * (1.5 - 0.5 * piv * y * y);
+			y = y * (1.5 - 0.5 * piv * y * y);
+			const bool live = K < n;
+			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
+			const double mk = live ? mm[u] * y : 0.0;
+			static_for<u + 1, 4>([&](auto vv) {
+				constexpr int v = decltype(vv)::value;
+				const double rkv = bcast_lane_f64(rk, K0 + v);   // R[K][K0+v]
+				g[v] = fma(-rkv, rk, g[v]);
+				mm[v] = fma(-rkv, mk, mm[v]);
+			});
+			rr[u * 64 + j] = rk;
+			mr[u * 64 + j] = mk;
+			if (live) {
+				Rf[K * 65 + j] = (float)rk;
+				if (j == 0) pv[K] = piv0;
+				if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mk : 0.0f;     // Z[j][K] = M[K][j]
+			}
+		});
 	}
 	__syncthreads();
-	const double rkj = rr[j], mkc = mr[j];
-	const int nlive = 16 - kk;                           // register rows that still exist
-	// branch-free inside a group of four: finished rows get a zero multiplier, all LDS reads issue back to back
+	double rkj[4], mkc[4];
 #pragma unroll
-	for (int gq = 0; gq < 4; gq++) {
-		if (4 * gq < nlive) {
-			double rki[4];
+	for (int u = 0; u < 4; u++) { rkj[u] = rr[u * 64 + j]; mkc[u] = mr[u * 64 + j]; }
+	const int nlive = 16 - 4 * kk;                       // register rows that still exist
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const int s = 4 * gq + u;
-				const int i = w + 4 * (kk + s);
-				const double v = rr[min(i, 63)];
-				rki[u] = (i > K && i < 64) ? v : 0.0;
-			}
+	for (int s = 0; s < 16; s++) {
+		if (s < nlive && !(s < 4 && w <= U)) {            // wave-uniform; slots 0..3 of waves <= U are finished rows
+			const int i = 16 * (kk + (s >> 2)) + 4 * w + (s & 3);
+			double acc_g = g[s], acc_m = mm[s];
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
-				const int s = 4 * gq + u;
-				g[s] = fma(-rki[u], rkj, g[s]);
-				mm[s] = fma(-rki[u], mkc, mm[s]);
+				const double rki = rr[u * 64 + i];           // R[K0+u][i]; rows i > K0+3 here
+				acc_g = fma(-rki, rkj[u], acc_g);
+				acc_m = fma(-rki, mkc[u], acc_m);
 			}
+			g[s] = acc_g; mm[s] = acc_m;
 		}
 	}
 }
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
                                                    const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio) {
 	__shared__ double Gs[64 * 65];               // symmetric G (assembly only): Gs[row * 65 + col]
 	__shared__ float Rf[64 * 65];                // R rows for the final store
-	__shared__ double Rrow[2 * 64], Mrow[2 * 64], dg[64], pv[64];
+	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
 	const int t = threadIdx.x;
 	const int j = t & 63, w = t >> 6;
 	const int NP = 16 * NT;
@@ -708,17 +720,17 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 	double g[16], mm[16];
 #pragma unroll
 	for (int s = 0; s < 16; s++) {
-		const int i = w + 4 * s;
+		const int i = 16 * (s >> 2) + 4 * w + (s & 3);
 		g[s] = Gs[i * 65 + j];
 		mm[s] = (i == j) ? 1.0 : 0.0;
 	}
 	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; }
 	__syncthreads();
 #pragma unroll 1
-	for (int kk = 0; kk < 16; kk++) {
-		static_for<0, 4>([&](auto u) { chol_step<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, z, pv, w, j, n, NP, kk); });
+	for (int kk = 0; kk < 4; kk++) {
+		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, z, pv, w, j, n, NP, kk); });
 #pragma unroll
-		for (int s = 0; s < 15; s++) { g[s] = g[s + 1]; mm[s] = mm[s + 1]; }   // next group's rows move to slot 0
+		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
 	}
 	__syncthreads();
 	// status[0]: 0 ok, 1 rejected: a pivot fell below min_ratio of its diagonal entry (2^-40 for the fp64 Gram matrix:
@@ -828,31 +840,38 @@ __global__ __launch_bounds__(256) void cross_finish_kernel(float* __restrict__ r
 // registers (same scheme as chol_kernel: M = R^-T, Z = M^T), one barrier per step.
 // ---------------------------------------------------------------------------------------------
 template <int U>
-__device__ __forceinline__ void trinv_step(double (&mm)[16], double* Mrow, const double* Rs, const double* rdiag,
-                                           float* __restrict__ z, int w, int j, int n, int NP, int kk) {
-	const int K = 4 * kk + U;
-	if (K >= n) return;                                  // uniform over the workgroup
-	double* mr = Mrow + (U & 1) * 64;
+__device__ __forceinline__ void trinv_group(double (&mm)[16], double* Mrow, const double* Rs, const double* rdiag,
+                                            float* __restrict__ z, int w, int j, int n, int NP, int kk) {
+	const int K0 = 16 * kk + 4 * U;
+	if (K0 >= n) return;                                 // uniform over the workgroup
+	double* mr = Mrow + (U & 1) * 256;                   // [4][64]
 	if (w == U) {
-		const double mk = mm[0] * rdiag[K];
-		mr[j] = mk;
-		if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mk : 0.0f;     // Z[j][K] = M[K][j]
+		static_for<0, 4>([&](auto uu) {
+			constexpr int u = decltype(uu)::value;
+			const int K = K0 + u;
+			const bool live = K < n;
+			const double mk = live ? mm[u] * rdiag[K] : 0.0;
+			static_for<u + 1, 4>([&](auto vv) {
+				constexpr int v = decltype(vv)::value;
+				mm[v] = fma(-Rs[K * 65 + K0 + v], mk, mm[v]);
+			});
+			mr[u * 64 + j] = mk;
+			if (live && j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mk : 0.0f;   // Z[j][K] = M[K][j]
+		});
 	}
 	__syncthreads();
-	const double mkc = mr[j];
-	const int nlive = 16 - kk;
+	double mkc[4];
 #pragma unroll
-	for (int gq = 0; gq < 4; gq++) {
-		if (4 * gq < nlive) {
-			double rki[4];
+	for (int u = 0; u < 4; u++) mkc[u] = mr[u * 64 + j];
+	const int nlive = 16 - 4 * kk;
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const int i = w + 4 * (kk + 4 * gq + u);
-				const double v = Rs[K * 65 + min(i, 63)];            // R[K][i]
-				rki[u] = (i > K && i < 64) ? v : 0.0;
-			}
+	for (int s = 0; s < 16; s++) {
+		if (s < nlive && !(s < 4 && w <= U)) {
+			const int i = 16 * (kk + (s >> 2)) + 4 * w + (s & 3);
+			double acc = mm[s];
 #pragma unroll
-			for (int u = 0; u < 4; u++) mm[4 * gq + u] = fma(-rki[u], mkc, mm[4 * gq + u]);
+			for (int u = 0; u < 4; u++) acc = fma(-Rs[(K0 + u) * 65 + i], mkc[u], acc);
+			mm[s] = acc;
 		}
 	}
 }
@@ -860,7 +879,7 @@ __device__ __forceinline__ void trinv_step(double (&mm)[16], double* Mrow, const
 __global__ __launch_bounds__(256) void trinv_kernel(float* __restrict__ z, const float* __restrict__ r, size_t ldr,
                                                     int n, int NP) {
 	__shared__ double Rs[64 * 65];               // Rs[row * 65 + col]
-	__shared__ double Mrow[2 * 64], rdiag[64];
+	__shared__ double Mrow[2 * 256], rdiag[64];
 	const int t = threadIdx.x;
 	const int j = t & 63, w = t >> 6;
 	for (int e = t; e < 64 * 64; e += 256) {
@@ -872,13 +891,13 @@ __global__ __launch_bounds__(256) void trinv_kernel(float* __restrict__ z, const
 	if (t < 64) rdiag[t] = (t < n) ? 1.0 / Rs[t * 65 + t] : 0.0;
 	double mm[16];
 #pragma unroll
-	for (int s = 0; s < 16; s++) mm[s] = (w + 4 * s == j) ? 1.0 : 0.0;
+	for (int s = 0; s < 16; s++) mm[s] = (16 * (s >> 2) + 4 * w + (s & 3) == j) ? 1.0 : 0.0;
 	__syncthreads();
 #pragma unroll 1
-	for (int kk = 0; kk < 16; kk++) {
-		static_for<0, 4>([&](auto u) { trinv_step<decltype(u)::value>(mm, Mrow, Rs, rdiag, z, w, j, n, NP, kk); });
+	for (int kk = 0; kk < 4; kk++) {
+		static_for<0, 4>([&](auto u) { trinv_group<decltype(u)::value>(mm, Mrow, Rs, rdiag, z, w, j, n, NP, kk); });
 #pragma unroll
-		for (int s = 0; s < 15; s++) mm[s] = mm[s + 1];
+		for (int s = 0; s < 12; s++) mm[s] = mm[s + 4];
 	}
 }
 
@@ -1060,7 +1079,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 				if (col < (UPD ? a.n_out : a.n)) {
 					float* dst = a.q + (size_t)col * a.ldq + row0 + 16 * rt + 4 * q;
 					if (full) {
+#ifdef TSQR_APPLY_NT_STORE
+						__builtin_nontemporal_store(acc[ct], reinterpret_cast<f32x4u*>(dst));   // streaming: do not evict A from the Infinity Cache
+#else
 						*reinterpret_cast<f32x4u*>(dst) = acc[ct];
+#endif
 					} else {
 #pragma unroll
 						for (int i = 0; i < 4; i++)
