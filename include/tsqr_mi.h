@@ -99,6 +99,12 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth,
                         void* wq, void* wr, float* gather_buf /* nranks*n*n floats */,
                         void* nccl_comm, int nranks, void* stream);
 
+/* Harness support (reference src/validation.cu:43-127, src/test.cu:147-165): accuracy metrics evaluated on the device in fp64.
+ * scratch: n*n + 8 doubles of device memory.  out_host[0..4] = ||Q^T Q - I||_F^2, its diagonal part, its off-diagonal part,
+ * ||Q R - A||_F^2, ||A||_F^2 (the last two only when r and a are given).  gram_out_host: optional n*n doubles receiving Q^T Q. */
+int tsqr_mi_validate_f32(const float* q, size_t ldq, const float* r, size_t ldr, const float* a, size_t lda,
+                         size_t m, size_t n, double* scratch, double* out_host, double* gram_out_host, void* stream);
+
 /* Optional timing of the engine's kernels with HIP events recorded on the caller's stream.  Classes:
  * 0 first fold level (streams A), 1 fold-tree levels, 2 triangular inverse, 3 apply (Q = A*inverse(R)),
  * 4 inter-panel coupling (n > 64), 5 other, 6 Gram matrix, 7 Gram reduction + Cholesky + inverse.  read() returns accumulated milliseconds and launch counts

@@ -21,6 +21,7 @@
 
 #include "../../include/tsqr_mi.h"
 #include "tsqr_kernels.hip"
+#include "validate.hip"
 
 namespace {
 
@@ -562,6 +563,27 @@ int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t l
 	float* wq = reinterpret_cast<float*>(wq_v);
 	const WqLayout L = wq_layout(m, n);
 	return apply_rinv(engine, q, ldq, a, lda, nullptr, 0, m, n, wq + L.z, reinterpret_cast<hipStream_t>(stream), /*z_ready=*/true);
+}
+
+// ---- harness support: the reference's accuracy metrics evaluated on the device in fp64 (src/validation.cu, src/test.cu:147-165) ----
+// scratch: (n*n + 8) doubles of device memory; out_host[0..4] = ||Q^T Q - I||_F^2, its diagonal part, its off-diagonal part,
+// ||Q R - A||_F^2, ||A||_F^2.  r / a may be null: then only the orthogonality sums are computed.  gram_out_host (n*n doubles) optional.
+int tsqr_mi_validate_f32(const float* q, size_t ldq, const float* r, size_t ldr, const float* a, size_t lda,
+                         size_t m, size_t n, double* scratch, double* out_host, double* gram_out_host, void* stream) {
+	if (m == 0 || n == 0 || n > m) return TSQR_MI_ERROR_INVALID_SIZE;
+	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+	double* g = scratch;
+	double* sums = scratch + n * n;
+	HIPCHK(hipMemsetAsync(scratch, 0, sizeof(double) * (n * n + 8), st));
+	const size_t rows_per_block = 32 * std::max<size_t>(1, cdiv(cdiv(m, 32), 2048));
+	hipLaunchKernelGGL(tsqrmi::gramd_kernel, dim3((unsigned)cdiv(m, rows_per_block)), dim3(256), 0, st, g, q, ldq, m, (int)n, rows_per_block);
+	hipLaunchKernelGGL(tsqrmi::orth_sums_kernel, dim3(1), dim3(256), 0, st, sums, g, (int)n);
+	if (r && a) hipLaunchKernelGGL(tsqrmi::resid_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, sums, q, ldq, r, ldr, a, lda, m, (int)n);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out_host, sums, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+	if (gram_out_host) HIPCHK(hipMemcpyAsync(gram_out_host, g, sizeof(double) * n * n, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	return 0;
 }
 
 size_t tsqr_mi_gram_elems(size_t n) { const size_t NT = np_of(n) / 16; return NT * (NT + 1) / 2 * 256; }
