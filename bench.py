@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--apply-waves", type=int, default=0)
     ap.add_argument("--policy", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true", help="use the row-partitioned driver even on one GPU")
+    ap.add_argument("--ld-pad", type=int, default=0, help="leading dimension = m + pad (experiments on DRAM channel mapping)")
     args = ap.parse_args()
 
     from tsqr_gpu_amd import blockqr as bq
@@ -136,22 +137,27 @@ def main():
     m_glob = m * world
     mode = bq.compute_mode[args.mode]
 
+    ld = m + args.ld_pad
     d_a = synth_block(m, n, m_glob, rank * m, 0, dev)
-    d_q = torch.empty(n, m, dtype=torch.float32, device=dev)
+    d_q = torch.empty(n, ld, dtype=torch.float32, device=dev)[:, :m]
+    if args.ld_pad:
+        a_pad = torch.zeros(n, ld, dtype=torch.float32, device=dev)
+        a_pad[:, :m] = d_a
+        d_a = a_pad[:, :m]
     d_r = torch.zeros(n, n, dtype=torch.float32, device=dev)
     if world == 1 and not args.force_dist:
         bf = bq.buffer(mode, bool(args.reorth), device=dev)
         bf.allocate(m, n)
 
         def step():
-            st = bq.qr(d_q, m, d_r, n, d_a, m, m, n, bf)
+            st = bq.qr(d_q, ld, d_r, n, d_a, ld, m, n, bf)
             assert st == 0, st
     else:
         from tsqr_gpu_amd import dist as tdist
         eng = tdist.HipEngine(mode, m, n, world)
 
         def step():
-            st = tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=bool(args.reorth))
+            st = tdist.qr_dist(d_q, ld, d_r, d_a, ld, m, n, eng, reorthogonalize=bool(args.reorth))
             assert st == 0, st
             torch.cuda.synchronize()                        # the single-GPU call is blocking; keep the same semantics
 

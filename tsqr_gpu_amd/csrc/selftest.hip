@@ -61,10 +61,10 @@ int tsqr_selftest_split(float* out, const float* in, int n) { hipLaunchKernelGGL
 extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, const double* gsum, int n, int NT, int reps) {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f);
+	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY);
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f);
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0.f;
@@ -222,5 +222,140 @@ extern "C" float tsqr_selftest_copy_time(float* q, const float* a, size_t m, int
 	(void)hipEventSynchronize(e1);
 	float ms = 0.f;
 	(void)hipEventElapsedTime(&ms, e0, e1);
+	return ms / reps;
+}
+
+// ---- access-pattern study: copy A -> Q with an explicit leading dimension ----
+// PAT 0: wave = 64 rows x 64 cols, 64-B segments per column per instruction ((c,q) layout, what apply/gram use)
+// PAT 2: workgroup = 256 rows x 64 cols, every wave instruction moves 1 KB contiguous of ONE column (wave w: columns w, w+4, ...)
+// PAT 3: workgroup = 256 rows x 64 cols, wave w: columns 16w .. 16w+15 (one column tile), 1 KB per instruction
+template <int PAT, bool INTER>
+__global__ __launch_bounds__(256) void copy_pat_kernel(float* q, const float* a, size_t ld, size_t m, int nunits, int upw, int nworkers) {
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if (PAT == 0) {
+		const int gw = blockIdx.x * 4 + wv;
+		if (gw >= nworkers) return;
+		const int c = lane & 15, qq = lane >> 4;
+		const int u_begin = INTER ? gw : gw * upw, u_end = INTER ? nunits : min(nunits, (gw + 1) * upw), u_step = INTER ? nworkers : 1;
+		for (int ch = u_begin; ch < u_end; ch += u_step) {
+			const size_t row0 = (size_t)ch * 64;
+			float p[4][16];
+			tsqrmi::load_chunk<4>(p, a, ld, row0, m, 64, c, qq);
+#pragma unroll
+			for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+				for (int rt = 0; rt < 4; rt++) {
+					tsqrmi::f32x4 v = {p[ct][4 * rt], p[ct][4 * rt + 1], p[ct][4 * rt + 2], p[ct][4 * rt + 3]};
+					*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)(16 * ct + c) * ld + row0 + 16 * rt + 4 * qq) = v;
+				}
+		}
+	} else {
+		const int wg = blockIdx.x;
+		const int u_begin = INTER ? wg : wg * upw, u_end = INTER ? nunits : min(nunits, (wg + 1) * upw), u_step = INTER ? nworkers : 1;
+		for (int b = u_begin; b < u_end; b += u_step) {
+			const size_t row0 = (size_t)b * 256;
+			tsqrmi::f32x4u v[16];
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const int col = PAT == 2 ? wv + 4 * k : 16 * wv + k;
+				v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)col * ld + row0 + 4 * lane);
+			}
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const int col = PAT == 2 ? wv + 4 * k : 16 * wv + k;
+				*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + 4 * lane) = v[k];
+			}
+		}
+	}
+}
+extern "C" float tsqr_selftest_copy_pat(float* q, const float* a, size_t ld, size_t m, int pat, int inter, int waves, int reps) {
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	int nunits, workers;
+	if (pat == 0) { nunits = (int)(m / 64); workers = waves; } else { nunits = (int)(m / 256); workers = waves / 4; }
+	const int upw = (nunits + workers - 1) / workers;
+	const int nworkers = (nunits + upw - 1) / upw;
+	const int grid = pat == 0 ? (nworkers + 3) / 4 : nworkers;
+	for (int it = 0; it < reps + 1; it++) {
+		if (it == 1) (void)hipEventRecord(e0, 0);
+		if (pat == 0 && !inter) hipLaunchKernelGGL((copy_pat_kernel<0, false>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
+		else if (pat == 0) hipLaunchKernelGGL((copy_pat_kernel<0, true>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
+		else if (pat == 2 && !inter) hipLaunchKernelGGL((copy_pat_kernel<2, false>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
+		else if (pat == 2) hipLaunchKernelGGL((copy_pat_kernel<2, true>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
+		else if (pat == 3 && !inter) hipLaunchKernelGGL((copy_pat_kernel<3, false>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
+		else hipLaunchKernelGGL((copy_pat_kernel<3, true>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
+	}
+	(void)hipEventRecord(e1, 0);
+	(void)hipEventSynchronize(e1);
+	float ms = 0.f;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	return ms / reps;
+}
+
+// ---- skeleton of a workgroup-cooperative streaming kernel: block = ROWS x 64 columns, global loads of ROWS*4 contiguous bytes
+// per column, transposition through LDS, next block prefetched into registers; output either as 64-B segments from the (c,q)
+// layout (OUT_LINEAR = false) or staged back through LDS and stored ROWS*4 contiguous bytes per column ----
+template <int ROWS, bool OUT_LINEAR>
+__global__ __launch_bounds__(256) void copy_wg_kernel(float* q, const float* a, size_t ld, size_t m, int nblocks, int nwg) {
+	constexpr int NP = 64, RS = ROWS + 4;
+	constexpr int LPC = ROWS / 4, CPI = 64 / LPC, NI = NP / (4 * CPI);
+	__shared__ __attribute__((aligned(16))) float As[NP * RS];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int c = lane & 15, qq = lane >> 4;
+	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
+	tsqrmi::f32x4u v[NI];
+	int b = blockIdx.x;
+	if (b < nblocks) {
+#pragma unroll
+		for (int k = 0; k < NI; k++) v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)b * ROWS + lrow);
+	}
+	for (; b < nblocks; b += nwg) {
+#pragma unroll
+		for (int k = 0; k < NI; k++) *reinterpret_cast<tsqrmi::f32x4*>(&As[((wv + 4 * k) * CPI + lcol) * RS + lrow]) = v[k];
+		__syncthreads();
+		const int bn = b + nwg;
+		if (bn < nblocks) {
+#pragma unroll
+			for (int k = 0; k < NI; k++) v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)bn * ROWS + lrow);
+		}
+		const size_t row0 = (size_t)b * ROWS;
+		if (!OUT_LINEAR) {
+#pragma unroll
+			for (int s = 0; s < ROWS / 64; s++)
+#pragma unroll
+				for (int ct = 0; ct < 4; ct++) {
+					const int r = wv * (ROWS / 4) + 16 * s + 4 * qq;
+					const tsqrmi::f32x4 x = *reinterpret_cast<const tsqrmi::f32x4*>(&As[(16 * ct + c) * RS + r]);
+					*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)(16 * ct + c) * ld + row0 + r) = x;
+				}
+		} else {
+#pragma unroll
+			for (int k = 0; k < NI; k++) {
+				const int col = (wv + 4 * k) * CPI + lcol;
+				const tsqrmi::f32x4 x = *reinterpret_cast<const tsqrmi::f32x4*>(&As[col * RS + lrow]);
+				*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + lrow) = x;
+			}
+		}
+		__syncthreads();
+	}
+}
+extern "C" float tsqr_selftest_copy_wg(float* q, const float* a, size_t ld, size_t m, int rows, int out_linear, int nwg, int reps) {
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	const int nblocks = (int)(m / rows);
+	if (nwg > nblocks) nwg = nblocks;
+	for (int it = 0; it < reps + 1; it++) {
+		if (it == 1) (void)hipEventRecord(e0, 0);
+		if (rows == 256 && out_linear) hipLaunchKernelGGL((copy_wg_kernel<256, true>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
+		else if (rows == 256) hipLaunchKernelGGL((copy_wg_kernel<256, false>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
+		else if (out_linear) hipLaunchKernelGGL((copy_wg_kernel<128, true>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
+		else hipLaunchKernelGGL((copy_wg_kernel<128, false>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
+	}
+	(void)hipEventRecord(e1, 0);
+	(void)hipEventSynchronize(e1);
+	float ms = 0.f;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	return ms / reps;
 }

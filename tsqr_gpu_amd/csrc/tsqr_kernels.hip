@@ -488,9 +488,13 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	}
 	if (gw < a.nwaves) {
 		float p[NT][16];
-		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
+#ifndef TSQR_BLOCKED_CHUNKS
+		const int ch_end = a.nchunks, ch_step = a.nwaves, ch_begin = gw;
+#else
+		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw), ch_step = 1, ch_begin = gw * a.cpw;
+#endif
 		int since_flush = 0;
-		for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+		for (int ch = ch_begin; ch < ch_end; ch += ch_step) {
 			load_chunk<NT>(p, a.a, a.lda, (size_t)ch * 64, a.m, a.n, c, q);
 #pragma unroll
 			for (int kt = 0; kt < 2; kt++) {             // K-step of 32 rows: registers 8kt .. 8kt+7 of every lane
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 						}
 				}
 			}
-			if (++since_flush == TSQR_GRAM_FLUSH || ch + 1 == ch_end) {
+			if (++since_flush == TSQR_GRAM_FLUSH || ch + ch_step >= ch_end) {
 				since_flush = 0;
 #pragma unroll
 				for (int t = 0; t < NTRI; t++) {
@@ -570,6 +574,143 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 		for (int t = 0; t < NTRI; t++)
 #pragma unroll
 			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = dacc[t][r] + red[0][(t * 4 + r) * 64 + lane];
+	}
+}
+
+// gram_bf16_wg_kernel: the same Gram tiles, organised per WORKGROUP for the DRAM access pattern (see apply_wg_kernel):
+// a workgroup streams ROWS x NP blocks (interleaved over the grid) with loads of ROWS*4 contiguous bytes per column and
+// instruction into LDS As[col][row], the next block is prefetched into registers, and wave w takes rows
+// [w*ROWS/4, (w+1)*ROWS/4) of the block in K-steps of 32 rows: lane (c,q) reads rows 8q..8q+7 of column 16t+c (two
+// 16-byte LDS reads) -- both MFMA operands come from the same registers, so any row <-> k assignment is valid.
+// GramArgs: nchunks = number of row blocks, nwaves = number of workgroups (= gridDim.x), cpw unused.
+template <int NT, int ROWS>
+__global__ __launch_bounds__(256) void gram_bf16_wg_kernel(const GramArgs a) {
+	constexpr int NP = 16 * NT;
+	constexpr int NTRI = (NT * (NT + 1)) / 2;
+	constexpr int RS = ROWS + 4;
+	constexpr int LPC = ROWS / 4, CPI = 64 / LPC;
+	constexpr int NI = NP / (4 * CPI);
+	constexpr int KS = ROWS / 128;                       // K-steps (32 rows) per wave and block
+	constexpr int FLUSH = 2 * TSQR_GRAM_FLUSH;           // K-steps per MFMA accumulation chain (same length as gram_bf16_kernel)
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	float* As = reinterpret_cast<float*>(smem);
+	double* red = reinterpret_cast<double*>(smem);       // [2][NTRI*256], aliases As after the streaming loop
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int c = lane & 15, q = lane >> 4;
+	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
+	f32x4 acc[NTRI], tot[NTRI];
+#pragma unroll
+	for (int t = 0; t < NTRI; t++) {
+		acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+		tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+	}
+	const int nblk = a.nchunks, nwg = a.nwaves;
+	auto load_block = [&](f32x4 (&v)[NI], int b) {
+		const size_t row = (size_t)b * ROWS + lrow;
+#pragma unroll
+		for (int k = 0; k < NI; k++) {
+			const int col = (wv + 4 * k) * CPI + lcol;
+			v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+			if (col < a.n) {
+				const float* src = a.a + (size_t)col * a.lda + row;
+				if (row + 3 < a.m) v[k] = *reinterpret_cast<const f32x4u*>(src);
+				else {
+#pragma unroll
+					for (int i = 0; i < 4; i++)
+						if (row + i < a.m) v[k][i] = src[i];
+				}
+			}
+		}
+	};
+	f32x4 v[NI];
+	int since_flush = 0;
+	int bi = blockIdx.x;
+	if (bi < nblk) load_block(v, bi);
+	for (; bi < nblk; bi += nwg) {
+#pragma unroll
+		for (int k = 0; k < NI; k++) {
+			const int col = (wv + 4 * k) * CPI + lcol;
+			*reinterpret_cast<f32x4*>(&As[col * RS + lrow]) = v[k];
+		}
+		__syncthreads();
+		if (bi + nwg < nblk) load_block(v, bi + nwg);
+#pragma unroll
+		for (int ks = 0; ks < KS; ks++) {
+			const int rb = wv * (ROWS / 4) + 32 * ks + 8 * q;
+			bf16x8 oh[NT], om[NT], ol[NT];
+#pragma unroll
+			for (int t = 0; t < NT; t++) {
+				const f32x4 x0 = *reinterpret_cast<const f32x4*>(&As[(16 * t + c) * RS + rb]);
+				const f32x4 x1 = *reinterpret_cast<const f32x4*>(&As[(16 * t + c) * RS + rb + 4]);
+				u32x4 hh, mm, ll;
+				unsigned h, m, lo;
+				split3_pair(x0[0], x0[1], h, m, lo); hh[0] = h; mm[0] = m; ll[0] = lo;
+				split3_pair(x0[2], x0[3], h, m, lo); hh[1] = h; mm[1] = m; ll[1] = lo;
+				split3_pair(x1[0], x1[1], h, m, lo); hh[2] = h; mm[2] = m; ll[2] = lo;
+				split3_pair(x1[2], x1[3], h, m, lo); hh[3] = h; mm[3] = m; ll[3] = lo;
+				oh[t] = __builtin_bit_cast(bf16x8, hh);
+				om[t] = __builtin_bit_cast(bf16x8, mm);
+				ol[t] = __builtin_bit_cast(bf16x8, ll);
+			}
+#pragma unroll
+			for (int pass = 6 - TSQR_GRAM_TERMS; pass < 6; pass++) {
+				int idx = 0;
+#pragma unroll
+				for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+					for (int tj = ti; tj < NT; tj++) {
+						const bf16x8 av = (pass == 0 || pass == 4) ? om[ti] : ((pass == 2) ? ol[ti] : oh[ti]);
+						const bf16x8 bv = (pass == 0 || pass == 3) ? om[tj] : ((pass == 1) ? ol[tj] : oh[tj]);
+						acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[idx], 0, 0, 0);
+						idx++;
+					}
+			}
+		}
+		since_flush += KS;
+		if (since_flush >= FLUSH || bi + nwg >= nblk) {
+			since_flush = 0;
+#pragma unroll
+			for (int t = 0; t < NTRI; t++) {
+				tot[t] += acc[t];
+				acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+			}
+		}
+		__syncthreads();
+	}
+	// workgroup sum in fp64 (LDS aliases As: every wave has passed the loop's last barrier)
+	double dacc[NTRI][4];
+#pragma unroll
+	for (int t = 0; t < NTRI; t++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) dacc[t][r] = (double)tot[t][r];
+	if (wv >= 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[(size_t)(wv - 2) * NTRI * 256 + (t * 4 + r) * 64 + lane] = dacc[t][r];
+	}
+	__syncthreads();
+	if (wv < 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) dacc[t][r] += red[(size_t)wv * NTRI * 256 + (t * 4 + r) * 64 + lane];
+	}
+	__syncthreads();
+	if (wv == 1) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[(t * 4 + r) * 64 + lane] = dacc[t][r];
+	}
+	__syncthreads();
+	if (wv == 0) {
+		double* out = a.part + (size_t)blockIdx.x * NTRI * 256;
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = dacc[t][r] + red[(t * 4 + r) * 64 + lane];
 	}
 }
 
@@ -622,7 +763,7 @@ __global__ __launch_bounds__(256) void gram_reduce2_kernel(double* __restrict__ 
 // the register rows rotate by four so the active block is always slots 0..3.
 template <int U>
 __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* __restrict__ z,
-                                           double* pv, int w, int j, int n, int NP, int kk) {
+                                           double* pv, int w, int j, int n, int NP, int kk, double dgj, double& s_acc) {
 	const int K0 = 16 * kk + 4 * U;
 	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
 	double* rr = Rrow + (U & 1) * 256;                   // [4][64]
@@ -651,6 +792,7 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 				Rf[K * 65 + j] = (float)rk;
 				if (j == 0) pv[K] = piv0;
 				if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mk : 0.0f;     // Z[j][K] = M[K][j]
+				if (j <= K) s_acc = fma(dgj * mk, mk, s_acc);                        // sum of g_jj * Z[j][K]^2
 			}
 		});
 	}
@@ -676,7 +818,8 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 }
 
 __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
-                                                   const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio) {
+                                                   const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio,
+                                                   float max_scond) {
 	__shared__ double Gs[64 * 65];               // symmetric G (assembly only): Gs[row * 65 + col]
 	__shared__ float Rf[64 * 65];                // R rows for the final store
 	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
@@ -725,25 +868,34 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 		mm[s] = (i == j) ? 1.0 : 0.0;
 	}
 	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; }
+	const double dgj = Gs[j * 65 + j];
+	double s_acc = 0.0;
 	__syncthreads();
 #pragma unroll 1
 	for (int kk = 0; kk < 4; kk++) {
-		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, z, pv, w, j, n, NP, kk); });
+		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, z, pv, w, j, n, NP, kk, dgj, s_acc); });
 #pragma unroll
 		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
 	}
+	// scaled conditioning S = || D * inverse(R) ||_F^2 / n with D = diag(sqrt(g_jj)): 1 for orthogonal columns of any scaling,
+	// ~cond^2 of the column-scaled matrix otherwise.  An entry-wise error eps*sqrt(g_ii g_jj) of G perturbs Q^T Q by <= eps*n*S.
+	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
+	__syncthreads();
+	if (j == 0) Rrow[w] = s_acc;
 	__syncthreads();
 	// status[0]: 0 ok, 1 rejected: a pivot fell below min_ratio of its diagonal entry (2^-40 for the fp64 Gram matrix:
-	//            cond(A)^2 beyond fp64 Cholesky; 2^-5 for the bf16-split Gram matrix: its fp32 accumulation is only
-	//            good enough for nearly orthogonal columns)
-	// status[1]: bit pattern of the smallest pivot ratio (float) for diagnostics
+	//            cond(A)^2 beyond fp64 Cholesky; 2^-5 for the bf16-split Gram matrix) or S exceeds max_scond (bf16-split Gram
+	//            matrix only: its fp32 accumulation is good enough for nearly orthogonal columns only)
+	// status[1]: bit pattern of the smallest pivot ratio (float), status[2]: of S (float) -- diagnostics
 	if (w == 0) {
 		const double d0 = dg[j], p0 = pv[j];
 		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
 		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
 		if (j == 0) {
-			status[0] = (ratio > min_ratio) ? 0u : 1u;
+			const float scond = (float)(((Rrow[0] + Rrow[1]) + (Rrow[2] + Rrow[3])) / (double)n);
+			status[0] = (ratio > min_ratio && scond <= max_scond) ? 0u : 1u;     // NaN compares false -> rejected
 			status[1] = __builtin_bit_cast(unsigned, ratio);
+			status[2] = __builtin_bit_cast(unsigned, scond);
 		}
 	}
 	// R out (fp32, exact zeros below the diagonal)
@@ -957,8 +1109,12 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 	if (gw >= a.nwaves) return;
 
 	float* At = At_all + wv * NP * AS;
-	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
-	for (int chi = gw * a.cpw; chi < ch_end; chi++) {
+#ifndef TSQR_BLOCKED_CHUNKS
+	const int ch_end = a.nchunks, ch_step = a.nwaves, ch_begin = gw;
+#else
+	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw), ch_step = 1, ch_begin = gw * a.cpw;
+#endif
+	for (int chi = ch_begin; chi < ch_end; chi += ch_step) {
 #ifndef TSQR_APPLY_FORWARD
 		const int ch = a.nchunks - 1 - chi;              // last-touched rows of A first (Infinity-Cache reuse after the R pass)
 #else
@@ -1092,6 +1248,213 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 				}
 			}
 		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply_wg_kernel: the same product as apply_kernel, organised per WORKGROUP for the DRAM access pattern.
+// Measured (tools/pattern_bench*.py, 2^20 x 64, lda = 2^20): a wave that touches 64 columns x 256 B per chunk copies at
+// 4.4 TB/s, a workgroup that moves ROWS*4 contiguous bytes of ONE column per instruction (loads and stores) at 5.0-5.2 TB/s,
+// independent of the power-of-two column stride.  So:
+//   * a workgroup owns ROWS x NP blocks (interleaved over the grid); wave w loads columns {(w+4k)*CPI + ...}, each load
+//     instruction = ROWS*4 contiguous bytes per column, written to LDS as As[col][row] (row index XOR-swizzled by bit 3
+//     of the column so that the operand reads below are bank-conflict free);
+//   * the next block is prefetched into registers before the products of the current one start;
+//   * wave w multiplies rows [w*ROWS/4, (w+1)*ROWS/4): A operand = 4-byte LDS reads along k, products as in apply_kernel,
+//     the result tile overwrites the wave's own rows of As in place;
+//   * after a barrier the block leaves through the same linear mapping (UPD: + the C input, loaded linearly as well).
+// ApplyArgs: nchunks = number of row blocks, nwaves = number of workgroups, cpw unused.
+// ---------------------------------------------------------------------------------------------
+template <int ENGINE, int NT, bool UPD, int ROWS>
+__global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
+	constexpr int NP = 16 * NT;
+	constexpr int RS = ROWS + 4;                         // column stride of As (floats)
+	constexpr int LPC = ROWS / 4, CPI = 64 / LPC;        // lanes per column, columns per load instruction
+	constexpr int NI = NP / (4 * CPI);                   // load instructions per wave and block
+	constexpr int SL = ROWS / 64;                        // 16-row slabs per wave
+	constexpr int ZS = NP + 16;
+	constexpr int KT = (NP + 31) / 32;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	float* As = reinterpret_cast<float*>(smem);
+	char* zbase = smem + sizeof(float) * NP * RS;
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int c = lane & 15, q = lane >> 4;
+	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
+
+	if constexpr (ENGINE == 0) {
+		float* Zs = reinterpret_cast<float*>(zbase);
+		for (int idx = threadIdx.x; idx < NP * NP; idx += 256) {
+			const int k = idx % NP, j = idx / NP;
+			Zs[k * ZS + j] = a.z[(size_t)j * NP + k];
+		}
+	} else {
+		unsigned short* Zb = reinterpret_cast<unsigned short*>(zbase);
+		for (int idx = threadIdx.x; idx < KT * NT * 64 * 8; idx += 256) {
+			const int jj = idx & 7, l = (idx >> 3) & 63, ct = (idx >> 9) % NT, kt = (idx >> 9) / NT;
+			const int k = 32 * kt + 8 * (l >> 4) + jj, j = 16 * ct + (l & 15);
+			const float v = (k < NP) ? a.z[(size_t)j * NP + k] : 0.0f;
+			unsigned h, m, lo;
+			split3(v, h, m, lo);
+			const int o = ((kt * NT + ct) * 64 + l) * 8 + jj;
+			Zb[0 * KT * NT * 512 + o] = (unsigned short)h;
+			Zb[1 * KT * NT * 512 + o] = (unsigned short)m;
+			Zb[2 * KT * NT * 512 + o] = (unsigned short)lo;
+		}
+	}
+
+	const int nblk = a.nchunks, nwg = a.nwaves;
+	auto blk = [&](int i) {
+#ifndef TSQR_APPLY_FORWARD
+		return nblk - 1 - i;                             // last-touched rows of A first (Infinity-Cache reuse after the R pass)
+#else
+		return i;
+#endif
+	};
+	auto swz = [](int col) { return ((col >> 3) & 1) << 4; };
+	auto load_block = [&](f32x4 (&v)[NI], const float* base, size_t ld, int ncols, int b) {
+		const size_t row = (size_t)b * ROWS + lrow;
+#pragma unroll
+		for (int k = 0; k < NI; k++) {
+			const int col = (wv + 4 * k) * CPI + lcol;
+			v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+			if (col < ncols) {
+				const float* src = base + (size_t)col * ld + row;
+				if (row + 3 < a.m) v[k] = *reinterpret_cast<const f32x4u*>(src);
+				else {
+#pragma unroll
+					for (int i = 0; i < 4; i++)
+						if (row + i < a.m) v[k][i] = src[i];
+				}
+			}
+		}
+	};
+
+	f32x4 v[NI];
+	int bi = blockIdx.x;
+	if (bi < nblk) load_block(v, a.a, a.lda, a.n, blk(bi));
+	for (; bi < nblk; bi += nwg) {
+		const int b = blk(bi);
+#pragma unroll
+		for (int k = 0; k < NI; k++) {
+			const int col = (wv + 4 * k) * CPI + lcol;
+			*reinterpret_cast<f32x4*>(&As[col * RS + (lrow ^ swz(col))]) = v[k];
+		}
+		__syncthreads();                                 // (also orders the Z image on the first pass)
+		if (bi + nwg < nblk) load_block(v, a.a, a.lda, a.n, blk(bi + nwg));
+		f32x4 cin[UPD ? NI : 1];
+		if constexpr (UPD) load_block(cin, a.q, a.ldq, a.n_out, b);
+
+#pragma unroll
+		for (int s = 0; s < SL; s++) {
+			const int rb = wv * (ROWS / 4) + 16 * s;
+			f32x4 acc[NT];
+#pragma unroll
+			for (int ct = 0; ct < NT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+			if constexpr (ENGINE == 0) {
+				const float* Zs = reinterpret_cast<const float*>(zbase);
+#pragma unroll
+				for (int t = 0; t < NP / 4; t++) {
+					const int k = 4 * t + q;
+					const float av = As[k * RS + ((rb + c) ^ swz(k))];
+#pragma unroll
+					for (int ct = 0; ct < NT; ct++) {
+						if (UPD || 4 * t <= 16 * ct + 15) {
+							const float bv = Zs[k * ZS + 16 * ct + c];
+							acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ct], 0, 0, 0);
+						}
+					}
+				}
+			} else {
+				const unsigned short* Zb = reinterpret_cast<const unsigned short*>(zbase);
+				constexpr int PS = KT * NT * 512;
+				bf16x8 ah[KT], am[KT], al[KT];
+				{
+					float x[8 * KT];
+					unsigned hh[4 * KT], mm[4 * KT], ll[4 * KT];
+#pragma unroll
+					for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+						for (int e = 0; e < 8; e++) {
+							const int k0 = 32 * kt + 8 * q + e;
+							x[8 * kt + e] = (k0 < NP) ? As[k0 * RS + ((rb + c) ^ swz(k0))] : 0.0f;
+						}
+					split3_pairs<4 * KT>(x, hh, mm, ll);
+#pragma unroll
+					for (int kt = 0; kt < KT; kt++) {
+						ah[kt] = __builtin_bit_cast(bf16x8, u32x4{hh[4 * kt], hh[4 * kt + 1], hh[4 * kt + 2], hh[4 * kt + 3]});
+						am[kt] = __builtin_bit_cast(bf16x8, u32x4{mm[4 * kt], mm[4 * kt + 1], mm[4 * kt + 2], mm[4 * kt + 3]});
+						al[kt] = __builtin_bit_cast(bf16x8, u32x4{ll[4 * kt], ll[4 * kt + 1], ll[4 * kt + 2], ll[4 * kt + 3]});
+					}
+				}
+				auto pair = [&](auto KTc, auto CTc, auto KTd, auto CTd) {
+					constexpr int k0 = decltype(KTc)::value, c0 = decltype(CTc)::value;
+					constexpr int k1 = decltype(KTd)::value, c1 = decltype(CTd)::value;
+					const int o0 = ((k0 * NT + c0) * 64 + lane) * 8, o1 = ((k1 * NT + c1) * 64 + lane) * 8;
+					const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(&Zb[0 * PS + o0]);
+					const bf16x8 bm0 = *reinterpret_cast<const bf16x8*>(&Zb[1 * PS + o0]);
+					const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(&Zb[2 * PS + o0]);
+					const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(&Zb[0 * PS + o1]);
+					const bf16x8 bm1 = *reinterpret_cast<const bf16x8*>(&Zb[1 * PS + o1]);
+					const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(&Zb[2 * PS + o1]);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k0], bm0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k1], bm1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bl0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bl1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k0], bh0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k1], bh1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bm0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bm1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k0], bh0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k1], bh1, acc[c1], 0, 0, 0);
+					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bh0, acc[c0], 0, 0, 0);
+					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bh1, acc[c1], 0, 0, 0);
+				};
+				using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+				using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+				if constexpr (NT == 1) {
+					pair(I0{}, I0{}, I0{}, I0{});
+					acc[0] = acc[0] * 0.5f;
+				} else if constexpr (NT == 2) {
+					pair(I0{}, I0{}, I0{}, I1{});
+				} else if constexpr (NT == 3) {
+					pair(I0{}, I0{}, I0{}, I1{});
+					pair(I0{}, I2{}, I1{}, I2{});
+				} else {
+					pair(I0{}, I0{}, I0{}, I1{});
+					pair(I0{}, I2{}, I0{}, I3{});
+					pair(I1{}, I2{}, I1{}, I3{});
+					if constexpr (UPD) pair(I1{}, I0{}, I1{}, I1{});
+				}
+			}
+			// the result tile replaces this wave's rows of As (same swizzle): D layout col = 16ct + c, rows rb + 4q + i
+#pragma unroll
+			for (int ct = 0; ct < NT; ct++) {
+				const int col = 16 * ct + c;
+				*reinterpret_cast<f32x4*>(&As[col * RS + ((rb + 4 * q) ^ swz(col))]) = acc[ct];
+			}
+		}
+		__syncthreads();
+		{
+			const size_t row = (size_t)b * ROWS + lrow;
+			const int nout = UPD ? a.n_out : a.n;
+#pragma unroll
+			for (int k = 0; k < NI; k++) {
+				const int col = (wv + 4 * k) * CPI + lcol;
+				if (col < nout) {
+					f32x4 x = *reinterpret_cast<const f32x4*>(&As[col * RS + (lrow ^ swz(col))]);
+					if constexpr (UPD) x += cin[k];
+					float* dst = a.q + (size_t)col * a.ldq + row;
+					if (row + 3 < a.m) *reinterpret_cast<f32x4u*>(dst) = x;
+					else {
+#pragma unroll
+						for (int i = 0; i < 4; i++)
+							if (row + i < a.m) dst[i] = x[i];
+					}
+				}
+			}
+		}
+		__syncthreads();
 	}
 }
 

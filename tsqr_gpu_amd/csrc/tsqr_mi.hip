@@ -35,6 +35,12 @@ int g_gram_level = 2;    // first Gram level tried: 2 bf16-split (then fp64), 1 
 constexpr int GRAM_NSPLIT = 16;
 int g_gram_waves = 2048;
 int g_apply_waves = 2048;
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+int g_apply_impl = env_int("TSQR_MI_APPLY_IMPL", 1);   // 0: per-wave chunks (apply_kernel), 1: workgroup blocks of 128 rows, 2: of 256 rows
+int g_apply_wgs = env_int("TSQR_MI_APPLY_WGS", 512);
+float g_bf16_max_scond = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);   // acceptance bound of the bf16 Gram level on S (chol_kernel)
+int g_debug = env_int("TSQR_MI_DEBUG", 0);
+int g_gram_impl = env_int("TSQR_MI_GRAM_IMPL", 0);     // bf16 Gram: 0 per-wave chunks, 1 workgroup blocks of 128 rows, 2 of 256 rows
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
 enum { KC_FOLD0 = 0, KC_TREE = 1, KC_TRINV = 2, KC_APPLY = 3, KC_COUPLE = 4, KC_MISC = 5, KC_GRAM = 6, KC_CHOL = 7, KC_COUNT = 8 };
@@ -205,9 +211,26 @@ int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n
 	return 0;
 }
 
-template <int NT> void launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool bf16, hipStream_t st) {
+template <int NT, int ROWS> void launch_gram_wg(tsqrmi::GramArgs a, int nblocks, hipStream_t st) {
+	constexpr int NP = 16 * NT, NTRI = NT * (NT + 1) / 2;
+	const size_t lds = std::max(sizeof(float) * NP * (ROWS + 4), sizeof(double) * 2 * NTRI * 256);
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_bf16_wg_kernel<NT, ROWS>),
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		attr_done = true;
+	}
+	const size_t nblk = cdiv(a.m, (size_t)ROWS);
+	a.nchunks = (int)nblk;
+	a.nwaves = (int)std::min<size_t>(nblk, (size_t)nblocks);   // never more workgroups than the partial buffer was sized for
+	hipLaunchKernelGGL((tsqrmi::gram_bf16_wg_kernel<NT, ROWS>), dim3(a.nwaves), dim3(256), lds, st, a);
+}
+template <int NT> int launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool bf16, hipStream_t st) {
+	if (bf16 && g_gram_impl == 1) { launch_gram_wg<NT, 128>(a, nblocks, st); return std::min<int>(nblocks, (int)cdiv(a.m, (size_t)128)); }
+	if (bf16 && g_gram_impl == 2) { launch_gram_wg<NT, 256>(a, nblocks, st); return std::min<int>(nblocks, (int)cdiv(a.m, (size_t)256)); }
 	if (bf16) hipLaunchKernelGGL(tsqrmi::gram_bf16_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
 	else hipLaunchKernelGGL(tsqrmi::gram_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
+	return nblocks;
 }
 
 // Gram engine: R (n x n, ldr) and Z = inverse(R) (NP x NP in z_buf) of src (m x n); status -> wq[L.status]
@@ -219,23 +242,24 @@ int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float*
 	tsqrmi::GramArgs a{};
 	a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
 	a.part = reinterpret_cast<double*>(wr);
+	int nparts = g.nblocks;                              // workgroups that wrote a partial
 	{
 		ProfScope ps(KC_GRAM, st);
 		switch (NT) {
-			case 1: launch_gram<1>(a, g.nblocks, bf16, st); break;
-			case 2: launch_gram<2>(a, g.nblocks, bf16, st); break;
-			case 3: launch_gram<3>(a, g.nblocks, bf16, st); break;
-			default: launch_gram<4>(a, g.nblocks, bf16, st); break;
+			case 1: nparts = launch_gram<1>(a, g.nblocks, bf16, st); break;
+			case 2: nparts = launch_gram<2>(a, g.nblocks, bf16, st); break;
+			case 3: nparts = launch_gram<3>(a, g.nblocks, bf16, st); break;
+			default: nparts = launch_gram<4>(a, g.nblocks, bf16, st); break;
 		}
 	}
 	HIPCHK(hipGetLastError());
 	const int nelem = g.ntri * 256;
-	const int nsplit = std::min(GRAM_NSPLIT, g.nblocks);
+	const int nsplit = std::min(GRAM_NSPLIT, nparts);
 	double* sub = reinterpret_cast<double*>(wq + L.gsub);
 	{
 		ProfScope ps(KC_CHOL, st);
 		hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
-		                   sub, a.part, g.nblocks, nelem, nsplit);
+		                   sub, a.part, nparts, nelem, nsplit);
 		hipLaunchKernelGGL(tsqrmi::gram_reduce2_kernel, dim3((nelem + 255) / 256), dim3(256), 0, st, gsum, sub, nelem, nsplit);
 	}
 	HIPCHK(hipGetLastError());
@@ -249,7 +273,7 @@ int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t n
 		ProfScope ps(KC_CHOL, st);
 		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
 		                   reinterpret_cast<unsigned*>(wq + L.status), gsum, (int)n, NT, bf16 ? 1 : 0,
-		                   bf16 ? 0.03125f : 9.094947017729282e-13f);
+		                   bf16 ? 0.03125f : 9.094947017729282e-13f, bf16 ? g_bf16_max_scond : INFINITY);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -277,12 +301,34 @@ template <int E, int NT, bool UPD = false> int launch_apply(const tsqrmi::ApplyA
 	hipLaunchKernelGGL((tsqrmi::apply_kernel<E, NT, UPD>), dim3(blocks), dim3(256), lds, st, a);
 	return 0;
 }
+// workgroup-cooperative variant (apply_wg_kernel): args.nchunks = row blocks of ROWS, args.nwaves = workgroups
+template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyArgs a, hipStream_t st) {
+	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
+	const size_t lds = sizeof(float) * NP * (ROWS + 4) + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)3 * KT * NT * 512 * 2);
+	static bool attr_done = false;
+	if (!attr_done) {
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>),
+		                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		attr_done = true;
+	}
+	const size_t nblk = cdiv(a.m, (size_t)ROWS);
+	a.nchunks = (int)nblk;
+	a.nwaves = (int)std::min<size_t>(nblk, (size_t)g_apply_wgs);
+	a.cpw = 0;
+	hipLaunchKernelGGL((tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>), dim3(a.nwaves), dim3(256), lds, st, a);
+	return 0;
+}
+template <int E, int NT, bool UPD> int launch_apply_any(const tsqrmi::ApplyArgs& a, hipStream_t st) {
+	if (g_apply_impl == 1) return launch_apply_wg<E, NT, UPD, 128>(a, st);
+	if (g_apply_impl == 2) return launch_apply_wg<E, NT, UPD, 256>(a, st);
+	return launch_apply<E, NT, UPD>(a, st);
+}
 template <int E> int dispatch_apply_nt(int NT, const tsqrmi::ApplyArgs& a, hipStream_t st) {
 	switch (NT) {
-		case 1: return launch_apply<E, 1>(a, st);
-		case 2: return launch_apply<E, 2>(a, st);
-		case 3: return launch_apply<E, 3>(a, st);
-		default: return launch_apply<E, 4>(a, st);
+		case 1: return launch_apply_any<E, 1, false>(a, st);
+		case 2: return launch_apply_any<E, 2, false>(a, st);
+		case 3: return launch_apply_any<E, 3, false>(a, st);
+		default: return launch_apply_any<E, 4, false>(a, st);
 	}
 }
 
@@ -321,6 +367,14 @@ int engine_of(int mode) {
 
 // read the Gram engine's status word (0 ok / 1 breakdown) after draining the stream
 int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStream_t st, unsigned* out) {
+	if (g_debug) {
+		unsigned w3[3];
+		HIPCHK(hipStreamSynchronize(st));
+		HIPCHK(hipMemcpy(w3, wq + L.status, sizeof(w3), hipMemcpyDeviceToHost));
+		float ratio, scond;
+		memcpy(&ratio, &w3[1], 4); memcpy(&scond, &w3[2], 4);
+		fprintf(stderr, "[tsqr_mi] chol status %u  min pivot ratio %.4g  scaled cond S %.4g\n", w3[0], ratio, scond);
+	}
 	if (h_pinned) {
 		HIPCHK(hipMemcpyAsync(h_pinned, wq + L.status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
@@ -389,7 +443,7 @@ int sweep(int engine, int r_engine, bool check_now, float* q, size_t ldq, float*
 			ua.cpw = (int)std::max<size_t>(1, cdiv(nch, (size_t)g_apply_waves));
 			ua.nchunks = (int)nch;
 			ua.nwaves = (int)cdiv(nch, (size_t)ua.cpw);
-			const int rc2 = (engine == 0) ? launch_apply<0, 4, true>(ua, st) : launch_apply<1, 4, true>(ua, st);
+			const int rc2 = (engine == 0) ? launch_apply_any<0, 4, true>(ua, st) : launch_apply_any<1, 4, true>(ua, st);
 			if (rc2) return rc2;
 			HIPCHK(hipGetLastError());
 		}
