@@ -40,7 +40,7 @@ def test_size_helpers(bq, oracle):
     # batch rule identical to the reference (src/tsqr.cu:39-44); working sizes never below the reference's
     for m in (1, 32, 33, 128, 1999, 9211, 1 << 15, 1 << 20, (1 << 20) + 1, 1 << 23):
         assert bq.get_batch_size_log2(m) == oracle.lib().ref_get_batch_size_log2(m)
-        assert bq.get_working_l_size(m) == oracle.lib().ref_working_l_size(m)
+        assert bq.get_working_l_size(m) == max(oracle.lib().ref_working_l_size(m), 8)   # never smaller than the reference; >= the 3 status words
         for n in (1, 7, 16, 51, 64, 100, 128):
             if n > m:
                 continue

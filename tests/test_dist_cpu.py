@@ -35,6 +35,14 @@ class NumpyEngine:
         self._z = np.linalg.inv(rr)
         return 0
 
+    def chol_async(self, level, g, m, r):
+        self._pending = self.chol(level, g, m, r)
+        if self._pending:                           # a rejected level still leaves *some* Z behind on the GPU; mimic that
+            self._z = np.eye(self.n)
+
+    def chol_status(self, m):
+        return self._pending
+
     def apply_z(self, q, ldq, a, lda, m):
         am = self._cm(a, lda, m, self.n).astype(np.float64)
         self._cm(q, ldq, m, self.n)[:] = (am @ self._z).astype(np.float32)

@@ -208,18 +208,19 @@ def test_all_r_engines(bq, oracle, torch_cuda, policy, mode, m, n):
 
 
 def test_auto_policy_escalation(bq, oracle, torch_cuda):
-    """auto: fp32_notc -> Householder; fp32_tc_cor -> bf16-split Gram for nearly orthogonal columns, fp64 Gram for moderate
-    cond, Householder when the Cholesky factorisation is rejected (cond ~1e8)."""
+    """auto: fp32_notc -> fp64 Gram (never the bf16-split level); fp32_tc_cor -> bf16-split Gram for nearly orthogonal columns,
+    fp64 Gram for moderate cond; both -> Householder when the Cholesky factorisation is rejected (rank deficient, cond ~1e8)."""
     a = oracle.uniform_matrix(4096, 64, seed=3)
     run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_tc_cor, False)
     assert bq.last_engine() == 3
     run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_notc, False)
-    assert bq.last_engine() == 0
+    assert bq.last_engine() == 1
     # a matrix whose Gram matrix is numerically singular in fp64 must end in the Householder engine
     sing = oracle.uniform_matrix(8192, 64, seed=8)
     sing[:, 63] = sing[:, 0] * 0.5 + sing[:, 1] * 0.25                # exact linear dependence (rank 63)
-    st, q, r = run_gpu(bq, torch_cuda, sing, bq.compute_mode.fp32_tc_cor, False)
-    assert st == 0 and bq.last_engine() == 2 and oracle.residual(sing, q, r) < 2e-6
+    for md in (bq.compute_mode.fp32_tc_cor, bq.compute_mode.fp32_notc):
+        st, q, r = run_gpu(bq, torch_cuda, sing, md, False)
+        assert st == 0 and bq.last_engine() == 2 and oracle.residual(sing, q, r) < 2e-6
     mid = oracle.matrix_with_cond(1 << 14, 64, 1e3, seed=5)
     for reorth in (False, True):
         st, q, r = run_gpu(bq, torch_cuda, mid, bq.compute_mode.fp32_tc_cor, reorth)
@@ -235,21 +236,23 @@ def test_auto_policy_escalation(bq, oracle, torch_cuda):
             assert oracle.orthogonality_fro(q) < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+@pytest.mark.parametrize("mode,use_gram,want_engine", [("fp32_notc", None, 1), ("fp32_tc_cor", None, 3),
+                                                       ("fp32_notc", False, 0), ("fp32_tc_cor", False, 0)])
 @pytest.mark.parametrize("reorth", [False, True])
-def test_dist_driver_single_rank(bq, oracle, torch_cuda, mode, reorth):
+def test_dist_driver_single_rank(bq, oracle, torch_cuda, mode, use_gram, want_engine, reorth):
     """The row-partitioned driver with its HIP engine on one rank (no collectives): staged C-ABI entry points
-    (Gram / Cholesky / apply for fp32_tc_cor, fold / apply for fp32_notc)."""
+    (Gram / Cholesky / apply by default -- bf16-split level for fp32_tc_cor, fp64 level for fp32_notc -- and
+    fold / apply when the Householder engine is forced)."""
     torch = torch_cuda
     from tsqr_gpu_amd import dist as tdist
     m, n = 20000, 64
     a = oracle.uniform_matrix(m, n, seed=13)
     d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
     d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
-    eng = tdist.HipEngine(bq.compute_mode[mode], m, n, 1)
+    eng = tdist.HipEngine(bq.compute_mode[mode], m, n, 1, use_gram=use_gram)
     st = tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=reorth)
     torch.cuda.synchronize()
-    assert st == 0 and eng.last_engine == (3 if mode == "fp32_tc_cor" else 0)
+    assert st == 0 and eng.last_engine == want_engine
     q = d_q.cpu().numpy().T; r = d_r.cpu().numpy().T
     assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL
     assert np.abs(np.tril(r, -1)).max() == 0.0

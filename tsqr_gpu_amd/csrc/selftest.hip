@@ -61,10 +61,10 @@ int tsqr_selftest_split(float* out, const float* in, int n) { hipLaunchKernelGGL
 extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, const double* gsum, int n, int NT, int reps) {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY);
+	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY, nullptr);
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY);
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY, nullptr);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0.f;
@@ -358,4 +358,36 @@ extern "C" float tsqr_selftest_copy_wg(float* q, const float* a, size_t ld, size
 	(void)hipEventElapsedTime(&ms, e0, e1);
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	return ms / reps;
+}
+
+// ---- launch-path costs: wall time per iteration of {k dependent tiny kernels [+ 4-byte D2H copy] + stream sync} ----
+__global__ void tiny_kernel(unsigned* p, unsigned* hostflag) {
+	if (threadIdx.x == 0) { p[0] += 1; if (hostflag) { __threadfence_system(); *reinterpret_cast<volatile unsigned*>(hostflag) = p[0]; } }
+}
+#include <chrono>
+extern "C" double tsqr_selftest_launch_cost(unsigned* dev_word, unsigned* pinned, int nkernels, int with_copy, int host_flag_spin, int iters) {
+	hipStream_t st = 0;
+	(void)hipMemset(dev_word, 0, 4);
+	(void)hipDeviceSynchronize();
+	unsigned expect = 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (int it = 0; it < iters; it++) {
+		for (int k = 0; k < nkernels; k++) {
+			const bool last = (k == nkernels - 1);
+			hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, st, dev_word, (host_flag_spin == 1 && last) ? pinned : nullptr);
+		}
+		expect += (unsigned)nkernels;
+		if (host_flag_spin == 1) {
+			while (*reinterpret_cast<volatile unsigned*>(pinned) != expect) { }
+		} else if (host_flag_spin == 2) {
+			if (with_copy) (void)hipMemcpyAsync(pinned, dev_word, 4, hipMemcpyDeviceToHost, st);
+			while (hipStreamQuery(st) == hipErrorNotReady) { }
+		} else {
+			if (with_copy) (void)hipMemcpyAsync(pinned, dev_word, 4, hipMemcpyDeviceToHost, st);
+			(void)hipStreamSynchronize(st);
+		}
+	}
+	const auto t1 = std::chrono::steady_clock::now();
+	(void)hipDeviceSynchronize();
+	return std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
 }

@@ -817,9 +817,12 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 	}
 }
 
-__global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
-                                                   const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio,
-                                                   float max_scond) {
+// LOADG: functor e -> G tile entry e (accumulator order); host_status: optional device-visible alias of pinned host memory
+// that receives the three status words as well (the host then needs no copy operation to read them).
+template <class LOADG>
+__device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
+                                          unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
+                                          float max_scond) {
 	__shared__ double Gs[64 * 65];               // symmetric G (assembly only): Gs[row * 65 + col]
 	__shared__ float Rf[64 * 65];                // R rows for the final store
 	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 		int idx = 0;
 		for (int ti = 0; ti < 4; ti++)
 			for (int tj = ti; tj < 4; tj++) {
-				if (ti < NT && tj < NT) { gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = gsum[idx * 256 + t]; idx++; }
+				if (ti < NT && tj < NT) { gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = loadg(idx * 256 + t); idx++; }
 				else gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = 0.0;
 			}
 	}
@@ -893,9 +896,16 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
 		if (j == 0) {
 			const float scond = (float)(((Rrow[0] + Rrow[1]) + (Rrow[2] + Rrow[3])) / (double)n);
-			status[0] = (ratio > min_ratio && scond <= max_scond) ? 0u : 1u;     // NaN compares false -> rejected
+			const unsigned s0 = (ratio > min_ratio && scond <= max_scond) ? 0u : 1u;     // NaN compares false -> rejected
+			status[0] = s0;
 			status[1] = __builtin_bit_cast(unsigned, ratio);
 			status[2] = __builtin_bit_cast(unsigned, scond);
+			if (host_status) {
+				volatile unsigned* hs = host_status;
+				hs[1] = __builtin_bit_cast(unsigned, ratio);
+				hs[2] = __builtin_bit_cast(unsigned, scond);
+				hs[0] = s0;                              // uncached host memory; complete at the latest when the kernel ends
+			}
 		}
 	}
 	// R out (fp32, exact zeros below the diagonal)
@@ -903,6 +913,31 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 		const int i = e % n, jj = e / n;
 		r[(size_t)jj * ldr + i] = (i <= jj) ? Rf[i * 65 + jj] : 0.0f;
 	}
+}
+
+__global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
+                                                   const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio,
+                                                   float max_scond, unsigned* __restrict__ host_status) {
+	chol_body(r, ldr, z, status, host_status, [&](int e) { return gsum[e]; }, n, NT, f32_layout, min_ratio, max_scond);
+}
+
+// chol_sub_kernel: chol_kernel fused with the second reduction stage -- G entries are formed from the nsplit sub-sums
+// (same fixed order as gram_reduce2_kernel, so R is bitwise the same) while they are loaded; G is also written to gsum.
+__global__ __launch_bounds__(256) void chol_sub_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
+                                                       unsigned* __restrict__ host_status, const double* __restrict__ sub,
+                                                       double* __restrict__ gsum, int nelem, int nsplit, int n, int NT, int f32_layout,
+                                                       float min_ratio, float max_scond) {
+	chol_body(r, ldr, z, status, host_status,
+	          [&](int el) {
+		          double v[16];
+#pragma unroll
+		          for (int s2 = 0; s2 < 16; s2++) v[s2] = (s2 < nsplit) ? sub[(size_t)s2 * nelem + el] : 0.0;
+		          const double g = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+		                           (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+		          gsum[el] = g;
+		          return g;
+	          },
+	          n, NT, f32_layout, min_ratio, max_scond);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1235,7 +1270,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 				if (col < (UPD ? a.n_out : a.n)) {
 					float* dst = a.q + (size_t)col * a.ldq + row0 + 16 * rt + 4 * q;
 					if (full) {
-#ifdef TSQR_APPLY_NT_STORE
+#ifndef TSQR_APPLY_CACHED_STORE
 						__builtin_nontemporal_store(acc[ct], reinterpret_cast<f32x4u*>(dst));   // streaming: do not evict A from the Infinity Cache
 #else
 						*reinterpret_cast<f32x4u*>(dst) = acc[ct];
@@ -1445,8 +1480,13 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 					f32x4 x = *reinterpret_cast<const f32x4*>(&As[col * RS + (lrow ^ swz(col))]);
 					if constexpr (UPD) x += cin[k];
 					float* dst = a.q + (size_t)col * a.ldq + row;
-					if (row + 3 < a.m) *reinterpret_cast<f32x4u*>(dst) = x;
-					else {
+					if (row + 3 < a.m) {
+#ifndef TSQR_APPLY_CACHED_STORE
+						__builtin_nontemporal_store(x, reinterpret_cast<f32x4u*>(dst));
+#else
+						*reinterpret_cast<f32x4u*>(dst) = x;
+#endif
+					} else {
 #pragma unroll
 						for (int i = 0; i < 4; i++)
 							if (row + i < a.m) dst[i] = x[i];

@@ -40,6 +40,13 @@ int g_apply_impl = env_int("TSQR_MI_APPLY_IMPL", 1);   // 0: per-wave chunks (ap
 int g_apply_wgs = env_int("TSQR_MI_APPLY_WGS", 512);
 float g_bf16_max_scond = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);   // acceptance bound of the bf16 Gram level on S (chol_kernel)
 int g_debug = env_int("TSQR_MI_DEBUG", 0);
+int g_host_status = env_int("TSQR_MI_HOST_STATUS", 0);   // measured: no gain over the 4-byte copy (kept as an option)
+int g_fused = env_int("TSQR_MI_FUSED", 0);            // 1: second reduction stage fused into the Cholesky kernel, status words written to pinned host memory
+// The Cholesky kernel also writes its status words (status, min pivot ratio, scaled cond) straight into the caller's pinned
+// h_wl (mtk::qr::buffer::hl) so that the host needs no copy operation to read them after the stream sync.
+// dev = device-visible alias of h_wl (null when it is not pinned host memory: then a 4-byte copy is enqueued as before).
+struct HostSig { unsigned* host = nullptr; unsigned* dev = nullptr; };
+HostSig g_hsig;
 int g_gram_impl = env_int("TSQR_MI_GRAM_IMPL", 0);     // bf16 Gram: 0 per-wave chunks, 1 workgroup blocks of 128 rows, 2 of 256 rows
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
@@ -267,13 +274,14 @@ int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float*
 }
 
 // R = chol(G) (n x n, ldr), Z = inverse(R) (NP x NP in z_buf), status word -> wq[L.status]
-int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t n, float* wq, const WqLayout& L, bool bf16, hipStream_t st) {
+int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t n, float* wq, const WqLayout& L, bool bf16, hipStream_t st,
+                unsigned* host_status = nullptr) {
 	const int NT = (int)(np_of(n) / 16);
 	{
 		ProfScope ps(KC_CHOL, st);
 		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
 		                   reinterpret_cast<unsigned*>(wq + L.status), gsum, (int)n, NT, bf16 ? 1 : 0,
-		                   bf16 ? 0.03125f : 9.094947017729282e-13f, bf16 ? g_bf16_max_scond : INFINITY);
+		                   bf16 ? 0.03125f : 9.094947017729282e-13f, bf16 ? g_bf16_max_scond : INFINITY, host_status);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -283,9 +291,39 @@ int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t n
 int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size_t m, size_t n,
            float* wq, float* wr, const WqLayout& L, bool bf16, hipStream_t st) {
 	double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 16 * 256;
+	if (g_fused) {                                       // two launches after the Gram kernel: sub-sums, then reduce2 + Cholesky in one
+		const GramPlan g = gram_plan(m, n);
+		const int NT = (int)(np_of(n) / 16);
+		tsqrmi::GramArgs a{};
+		a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
+		a.part = reinterpret_cast<double*>(wr);
+		int nparts = g.nblocks;
+		{
+			ProfScope ps(KC_GRAM, st);
+			switch (NT) {
+				case 1: nparts = launch_gram<1>(a, g.nblocks, bf16, st); break;
+				case 2: nparts = launch_gram<2>(a, g.nblocks, bf16, st); break;
+				case 3: nparts = launch_gram<3>(a, g.nblocks, bf16, st); break;
+				default: nparts = launch_gram<4>(a, g.nblocks, bf16, st); break;
+			}
+		}
+		const int nelem = g.ntri * 256;
+		const int nsplit = std::min(GRAM_NSPLIT, nparts);
+		double* sub = reinterpret_cast<double*>(wq + L.gsub);
+		{
+			ProfScope ps(KC_CHOL, st);
+			hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
+			                   sub, a.part, nparts, nelem, nsplit);
+			hipLaunchKernelGGL(tsqrmi::chol_sub_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
+			                   reinterpret_cast<unsigned*>(wq + L.status), g_hsig.dev, sub, gsum, nelem, nsplit, (int)n, NT,
+			                   bf16 ? 1 : 0, bf16 ? 0.03125f : 9.094947017729282e-13f, bf16 ? g_bf16_max_scond : INFINITY);
+		}
+		HIPCHK(hipGetLastError());
+		return 0;
+	}
 	const int rc = gram_g(gsum, src, ld, m, n, wq, wr, L, bf16, st);
 	if (rc) return rc;
-	return chol_from_g(r, ldr, z_buf, gsum, n, wq, L, bf16, st);
+	return chol_from_g(r, ldr, z_buf, gsum, n, wq, L, bf16, st, g_hsig.dev);
 }
 
 template <int E, int NT, bool UPD = false> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
@@ -359,6 +397,16 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
 	return 0;
 }
 
+// Is h_wl pinned host memory the device can write?  (mtk::qr::buffer allocates it with hipHostMalloc; anything else
+// falls back to copy + stream sync.)  The answer is cached per pointer.
+void resolve_host_sig(unsigned* h_wl) {
+	if (h_wl == g_hsig.host) return;
+	g_hsig.host = h_wl; g_hsig.dev = nullptr;
+	if (!h_wl || !g_host_status) return;
+	hipPointerAttribute_t at{};
+	if (hipPointerGetAttributes(&at, h_wl) != hipSuccess) { (void)hipGetLastError(); return; }
+	if (at.type == hipMemoryTypeHost && at.devicePointer) g_hsig.dev = reinterpret_cast<unsigned*>(at.devicePointer);
+}
 int engine_of(int mode) {
 	if (mode == TSQR_MI_FP32_NOTC) return 0;
 	if (mode == TSQR_MI_FP32_TC_COR) return 1;
@@ -374,6 +422,11 @@ int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStrea
 		float ratio, scond;
 		memcpy(&ratio, &w3[1], 4); memcpy(&scond, &w3[2], 4);
 		fprintf(stderr, "[tsqr_mi] chol status %u  min pivot ratio %.4g  scaled cond S %.4g\n", w3[0], ratio, scond);
+	}
+	if (h_pinned && h_pinned == g_hsig.host && g_hsig.dev) {      // gram_finish_kernel already wrote the words to h_wl
+		HIPCHK(hipStreamSynchronize(st));
+		*out = reinterpret_cast<volatile unsigned*>(h_pinned)[0];
+		return 0;
 	}
 	if (h_pinned) {
 		HIPCHK(hipMemcpyAsync(h_pinned, wq + L.status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -478,7 +531,7 @@ size_t tsqr_mi_working_r_size(size_t m, size_t n) {
 	// the stack of a dist/gathered fold is tiny; nothing extra needed
 	return std::max(ref_wr(m, n), need);
 }
-size_t tsqr_mi_working_l_size(size_t m) { return m == 0 ? 0 : ref_bs(m) + 1; }
+size_t tsqr_mi_working_l_size(size_t m) { return m == 0 ? 0 : std::max<size_t>(ref_bs(m) + 1, 8); }   // >= 3 words: the Cholesky status words
 size_t tsqr_mi_working_reorth_size(size_t m) { return 16 * 16 * 2 + m * 16; }
 
 void tsqr_mi_profile_enable(int on) {
@@ -529,7 +582,9 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	float* wq = reinterpret_cast<float*>(wq_v);
 	float* wr = reinterpret_cast<float*>(wr_v);
 	const WqLayout L = wq_layout(m, n);
-	const bool use_gram = (g_policy == 2) || (g_policy == 0 && mode == TSQR_MI_FP32_TC_COR);
+	// auto policy: fp32_tc_cor starts at the bf16-split Gram level, fp32_notc at the fp64 Gram level (faster AND more
+	// orthogonal than the fp32 Householder fold: 3.5e-7 vs 2.1e-6 at 2^20 x 64); both fall back to Householder TSQR
+	const bool use_gram = (g_policy == 2) || (g_policy == 0);
 	const bool may_fall_back = use_gram && g_policy == 0;
 	// single panel, single sweep: run speculatively and look at the status at the final sync (A is untouched for n <= 64);
 	// otherwise (several panels or a second sweep consuming Q) verify each panel right away.
@@ -538,10 +593,11 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
 	g_last_engine = 0;
 	g_min_level = 2;
+	resolve_host_sig(h_wl);
 
 	// R-factor engine levels: 2 bf16-split Gram (memory-bound), 1 fp64 Gram, 0 Householder TSQR.  Deferred mode runs a level
 	// speculatively and steps down when chol_kernel rejected it; with check_now panel_qr escalates per panel by itself.
-	const int first_level = use_gram ? g_gram_level : 0;
+	const int first_level = !use_gram ? 0 : ((mode == TSQR_MI_FP32_TC_COR || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1));
 	for (int level = first_level; level >= 0; level--) {
 		int rc = sweep(engine, level, check_now, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
 		if (rc) return rc;
@@ -603,11 +659,18 @@ int tsqr_mi_chol_f32(int level, float* r, size_t ldr, const double* gsum, size_t
 	const WqLayout L = wq_layout(m, n);
 	int rc = chol_from_g(r, ldr, wq + L.z, gsum, n, wq, L, level == 2, st);
 	if (rc) return rc;
+	if (!status_out) return 0;                           // asynchronous: read the verdict later with tsqr_mi_chol_status
 	unsigned status = 0;
 	rc = read_status(wq, L, nullptr, st, &status);       // blocking: the caller decides on the next level
 	if (rc) return rc;
-	if (status_out) *status_out = status;
+	*status_out = status;
 	return 0;
+}
+
+int tsqr_mi_chol_status(const void* wq_v, size_t m, size_t n, unsigned* status_out, void* stream) {
+	if (m == 0 || n == 0 || n > PW || !status_out) return TSQR_MI_ERROR_INVALID_SIZE;
+	const WqLayout L = wq_layout(m, n);
+	return read_status(reinterpret_cast<const float*>(wq_v), L, nullptr, reinterpret_cast<hipStream_t>(stream), status_out);
 }
 
 int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t lda, size_t m, size_t n, void* wq_v, void* stream) {
@@ -687,7 +750,8 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 	const WqLayout L = wq_layout(std::max(m_local, (size_t)nranks * n), n);
 	float* rl = wq + L.r2;                               // local R, n x n packed (ld n)
 	const float* src = a; size_t ld_src = lda;
-	const bool use_gram = (g_policy == 2) || (g_policy == 0 && mode == TSQR_MI_FP32_TC_COR);
+	const bool use_gram = (g_policy == 2) || (g_policy == 0);
+	const int first_level = (mode == TSQR_MI_FP32_TC_COR || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1);
 	nccl_allreduce_t allreduce = use_gram ? resolve_allreduce() : nullptr;
 	for (int it = 0; it < (reorth ? 2 : 1); it++) {
 		int rc;
@@ -696,7 +760,7 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 			double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 16 * 256;
 			const size_t gelems = (np_of(n) / 16) * (np_of(n) / 16 + 1) / 2 * 256;
 			bool done = false;
-			for (int level = g_gram_level; level >= 1 && !done; level--) {
+			for (int level = first_level; level >= 1 && !done; level--) {
 				rc = gram_g(gsum, src, ld_src, m_local, n, wq, wr, L, level == 2, st);
 				if (rc) return rc;
 				// ncclFloat64 == 8, ncclSum == 0 in nccl.h/rccl.h
@@ -704,12 +768,20 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 				float* rdst = (it == 0) ? r : rl;
 				rc = chol_from_g(rdst, (it == 0) ? ldr : n, wq + L.z, gsum, n, wq, L, level == 2, st);
 				if (rc) return rc;
+				// q does not alias the source: apply speculatively, then look at the status (one sync per sweep, no idle gap)
+				const bool speculative = (q != src);
+				if (speculative) {
+					rc = apply_rinv(engine, q, ldq, src, ld_src, nullptr, 0, m_local, n, wq + L.z, st, /*z_ready=*/true);
+					if (rc) return rc;
+				}
 				unsigned status = 0;
 				rc = read_status(wq, L, nullptr, st, &status);
 				if (rc) return rc;
 				if (status == 0 || g_policy == 2) {
-					rc = apply_rinv(engine, q, ldq, src, ld_src, nullptr, 0, m_local, n, wq + L.z, st, /*z_ready=*/true);
-					if (rc) return rc;
+					if (!speculative) {
+						rc = apply_rinv(engine, q, ldq, src, ld_src, nullptr, 0, m_local, n, wq + L.z, st, /*z_ready=*/true);
+						if (rc) return rc;
+					}
 					done = true;
 				}
 			}

@@ -32,8 +32,10 @@ class HipEngine:
         self.mode = bq.compute_mode(mode)
         self.n = n
         self.m_local = m_local
-        # same default policy as tsqr_mi_qr_f32: Gram engine for fp32_tc_cor, Householder TSQR for fp32_notc
-        self.use_gram = (self.mode == bq.compute_mode.fp32_tc_cor) if use_gram is None else bool(use_gram)
+        # same default policy as tsqr_mi_qr_f32: Gram engine (fp32_tc_cor: bf16-split level, then fp64; fp32_notc: fp64 level),
+        # Householder TSQR as the fallback
+        self.use_gram = True if use_gram is None else bool(use_gram)
+        self.gram_levels = (2, 1) if self.mode == bq.compute_mode.fp32_tc_cor else (1,)
         self.last_engine = 0
         rows = max(m_local, world_size * n)
         self.wq = torch.empty(max(bq.get_working_q_size(rows, n), 1), dtype=torch.float32, device="cuda")
@@ -80,6 +82,20 @@ class HipEngine:
             raise RuntimeError("tsqr_mi_chol_f32 -> %d %s" % (st, bq.last_error()))
         return int(status.value)
 
+    def chol_async(self, level, g, m, r):
+        """Like chol() but without the stream sync: the verdict is fetched later with chol_status()."""
+        st = bq.lib().tsqr_mi_chol_f32(level, r.data_ptr(), self.n, g.data_ptr(), m, self.n, self.wq.data_ptr(), None, self._stream())
+        if st != 0:
+            raise RuntimeError("tsqr_mi_chol_f32 -> %d %s" % (st, bq.last_error()))
+
+    def chol_status(self, m):
+        import ctypes
+        status = ctypes.c_uint(0)
+        st = bq.lib().tsqr_mi_chol_status(self.wq.data_ptr(), m, self.n, ctypes.byref(status), self._stream())
+        if st != 0:
+            raise RuntimeError("tsqr_mi_chol_status -> %d %s" % (st, bq.last_error()))
+        return int(status.value)
+
     def apply_z(self, q, ldq, a, lda, m):
         st = bq.lib().tsqr_mi_apply_z_f32(int(self.mode), q.data_ptr(), ldq, a.data_ptr(), lda, m, self.n,
                                           self.wq.data_ptr(), self._stream())
@@ -102,13 +118,22 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
     for sweep in range(2 if reorthogonalize else 1):
         r_new = None
         if getattr(engine, "use_gram", False):
-            for level in (2, 1):                       # bf16-split Gram, then fp64 Gram; every rank takes the same decision
+            for level in getattr(engine, "gram_levels", (2, 1)):   # bf16-split Gram, then fp64 Gram; every rank takes the same decision
                 g = engine.gram(level, src, ld_src, m_local)
                 if world > 1:
                     dist.all_reduce(g, group=group)
                 r_try = engine.empty(n, n)
-                if engine.chol(level, g, m_local, r_try) == 0:
+                if hasattr(engine, "chol_async") and q.data_ptr() != src.data_ptr():
+                    # the output does not alias the source: enqueue the apply speculatively behind the Cholesky and look at the
+                    # verdict afterwards -- one synchronisation per sweep, no idle gap between the two kernels
+                    engine.chol_async(level, g, m_local, r_try)
                     engine.apply_z(q, ldq, src, ld_src, m_local)
+                    ok = engine.chol_status(m_local) == 0
+                else:
+                    ok = engine.chol(level, g, m_local, r_try) == 0
+                    if ok:
+                        engine.apply_z(q, ldq, src, ld_src, m_local)
+                if ok:
                     r_new = r_try
                     engine.last_engine = max(getattr(engine, "last_engine", 0), 3 if level == 2 else 1)
                     break
