@@ -149,8 +149,10 @@ def main():
         bf = bq.buffer(mode, bool(args.reorth), device=dev)
         bf.allocate(m, n)
 
+        call = bq.bind(d_q, ld, d_r, n, d_a, ld, m, n, bf)   # arguments marshalled once, as in a C++ caller's loop
+
         def step():
-            st = bq.qr(d_q, ld, d_r, n, d_a, ld, m, n, bf)
+            st = call()
             assert st == 0, st
     else:
         from tsqr_gpu_amd import dist as tdist

@@ -194,6 +194,30 @@ def qr(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize
     return st
 
 
+def bind(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
+    """qr() with every argument marshalled once: returns a zero-argument callable that issues exactly one C-ABI call
+    (tsqr_mi_qr_f32) per invocation -- what a C++ caller's loop looks like, without per-call Python/ctypes conversions.
+    The tensors, the buffer and the stream must stay alive and unchanged while the callable is in use."""
+    import torch
+    mode = bf.mode if mode is None else compute_mode(mode)
+    reorth = bf.reorthogonalize if reorthogonalize is None else bool(reorthogonalize)
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    fn = lib().tsqr_mi_qr_f32
+    args = (ci(int(mode)), ci(int(reorth)), vp(_ptr(q)), sz(ldq), vp(_ptr(r)), sz(ldr), vp(_ptr(a)), sz(lda), sz(m), sz(n),
+            vp(_ptr(bf.dwq)), vp(_ptr(bf.dwr)), vp(_ptr(bf.dw_reorth_r)), vp(_ptr(bf.dl)), vp(_ptr(bf.hl)), vp(stream.cuda_stream))
+    keep = (q, r, a, bf, stream)
+
+    def call():
+        st = fn(*args)
+        if st < 0:
+            raise RuntimeError("tsqr_mi_qr_f32 failed: %s" % last_error())
+        return st
+    call._keep = keep
+    return call
+
+
 def set_tuning(level0_waves=0, tree_chunks_per_wave=0):
     lib().tsqr_mi_set_tuning(level0_waves, tree_chunks_per_wave)
 

@@ -1511,6 +1511,12 @@ __global__ __launch_bounds__(256) void rmul_kernel(float* __restrict__ r, size_t
 	}
 }
 
+// completion signal: one thread stores seq to device-visible pinned host memory.  Enqueued behind the last kernel of a call
+// so that the host can spin on the word instead of paying a stream synchronisation (stream order makes it a full barrier).
+__global__ void host_flag_kernel(unsigned* __restrict__ host_flag, unsigned seq) {
+	*reinterpret_cast<volatile unsigned*>(host_flag) = seq;
+}
+
 __global__ __launch_bounds__(256) void copy2d_kernel(float* __restrict__ dst, size_t ldd, const float* __restrict__ src, size_t lds,
                                                      int rows, int cols) {
 	const size_t total = (size_t)rows * cols;

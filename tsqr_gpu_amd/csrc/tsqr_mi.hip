@@ -40,7 +40,8 @@ int g_apply_impl = env_int("TSQR_MI_APPLY_IMPL", 1);   // 0: per-wave chunks (ap
 int g_apply_wgs = env_int("TSQR_MI_APPLY_WGS", 512);
 float g_bf16_max_scond = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);   // acceptance bound of the bf16 Gram level on S (chol_kernel)
 int g_debug = env_int("TSQR_MI_DEBUG", 0);
-int g_host_status = env_int("TSQR_MI_HOST_STATUS", 0);   // measured: no gain over the 4-byte copy (kept as an option)
+int g_host_status = env_int("TSQR_MI_HOST_STATUS", 1);   // Cholesky status words written straight into the pinned h_wl
+int g_host_flag = env_int("TSQR_MI_HOST_FLAG", 1);       // end of call: spin on a pinned flag word instead of hipStreamSynchronize
 int g_fused = env_int("TSQR_MI_FUSED", 0);            // 1: second reduction stage fused into the Cholesky kernel, status words written to pinned host memory
 // The Cholesky kernel also writes its status words (status, min pivot ratio, scaled cond) straight into the caller's pinned
 // h_wl (mtk::qr::buffer::hl) so that the host needs no copy operation to read them after the stream sync.
@@ -407,6 +408,29 @@ void resolve_host_sig(unsigned* h_wl) {
 	if (hipPointerGetAttributes(&at, h_wl) != hipSuccess) { (void)hipGetLastError(); return; }
 	if (at.type == hipMemoryTypeHost && at.devicePointer) g_hsig.dev = reinterpret_cast<unsigned*>(at.devicePointer);
 }
+// End of a call on the fast path: a one-thread kernel behind the last kernel raises h_wl[3]; the host spins on it (about
+// 5 us cheaper than hipStreamSynchronize, tools/launch_cost.py) and polls the stream now and then so that a failed launch
+// cannot hang the caller.  Returns 1 when the flag path is not available (caller then synchronises the stream).
+unsigned g_seq = 0;
+int signal_and_wait(hipStream_t st) {
+	if (!g_host_flag || !g_hsig.dev || g_prof.on) return 1;
+	unsigned seq = ++g_seq;
+	if (seq == 0) seq = ++g_seq;
+	volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(g_hsig.host) + 3;
+	*flag = 0;
+	hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, st, g_hsig.dev + 3, seq);
+	if (hipGetLastError() != hipSuccess) return 1;
+	for (;;) {
+		for (int i = 0; i < 20000; i++) {
+			if (*flag == seq) return 0;
+			__builtin_ia32_pause();
+		}
+		const hipError_t e = hipStreamQuery(st);
+		if (e == hipSuccess) return 0;
+		if (e != hipErrorNotReady) HIPCHK(e);
+	}
+}
+
 int engine_of(int mode) {
 	if (mode == TSQR_MI_FP32_NOTC) return 0;
 	if (mode == TSQR_MI_FP32_TC_COR) return 1;
@@ -427,6 +451,11 @@ int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStrea
 		HIPCHK(hipStreamSynchronize(st));
 		*out = reinterpret_cast<volatile unsigned*>(h_pinned)[0];
 		return 0;
+	}
+	if (!h_pinned) {                                     // staged API: a library-owned pinned word (a pageable 4-byte copy costs ~15 us)
+		static unsigned* own = nullptr;
+		if (!own && hipHostMalloc(reinterpret_cast<void**>(&own), 64, hipHostMallocDefault) != hipSuccess) { own = nullptr; (void)hipGetLastError(); }
+		h_pinned = own;
 	}
 	if (h_pinned) {
 		HIPCHK(hipMemcpyAsync(h_pinned, wq + L.status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -614,8 +643,13 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 		HIPCHK(hipGetLastError());
 		if (level > 0 && deferred) {
 			unsigned status = 0;
-			rc = read_status(wq, L, h_wl, st, &status);
-			if (rc) return rc;
+			rc = signal_and_wait(st);
+			if (rc < 0) return rc;
+			if (rc == 0) status = reinterpret_cast<volatile unsigned*>(g_hsig.host)[0];   // written by the Cholesky kernel
+			else {
+				rc = read_status(wq, L, h_wl, st, &status);
+				if (rc) return rc;
+			}
 			if (status != 0) { g_min_level = 2; continue; }       // rejected: step down and redo
 		} else {
 			HIPCHK(hipStreamSynchronize(st));

@@ -122,7 +122,8 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
                 g = engine.gram(level, src, ld_src, m_local)
                 if world > 1:
                     dist.all_reduce(g, group=group)
-                r_try = engine.empty(n, n)
+                # first sweep: factor straight into the caller's r (a rejected level is simply overwritten by the next one)
+                r_try = r if sweep == 0 else engine.empty(n, n)
                 if hasattr(engine, "chol_async") and q.data_ptr() != src.data_ptr():
                     # the output does not alias the source: enqueue the apply speculatively behind the Cholesky and look at the
                     # verdict afterwards -- one synchronisation per sweep, no idle gap between the two kernels
@@ -153,7 +154,8 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
                 r_new = r_loc
             engine.apply_rinv(q, ldq, src, ld_src, m_local, r_new)
         if sweep == 0:
-            r.copy_(r_new)
+            if r_new is not r:
+                r.copy_(r_new)
         else:
             engine.rmul(r, r_new)
         src, ld_src = q, ldq
