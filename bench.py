@@ -19,6 +19,28 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def usable_cpus():
+    """Host threads the CPU baseline may use: affinity mask, cgroup CPU quota, and at most 16 (the CPU share of a one-GPU
+    box on this pool -- os.cpu_count() reports the whole 256-thread host there, and oversubscribing slows OpenMP down)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+CPU_THREADS = usable_cpus()
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):   # before numpy / the oracle's libgomp load
+    os.environ.setdefault(_v, str(CPU_THREADS))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -61,11 +83,7 @@ def cpu_baseline(n, mode_name, sample_rows):
     t = time.time()
     st, q, r = ro.qr(a, md, False)
     dt = time.time() - t
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = int(os.environ.get("OMP_NUM_THREADS", CPU_THREADS))
     out = {"value": f_qr(sample_rows, n) / dt / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
            "sample": "oracle/ref_tsqr.c (%s, reference algorithm, OpenMP) on %d x %d U(-1,1), %.2f s; F_QR = 4MN^2 - 4/3 N^3" % (
                mode_name, sample_rows, n, dt),
