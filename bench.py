@@ -78,7 +78,7 @@ def cpu_baseline(n, mode_name, sample_rows):
     LAPACK (scipy) on a bounded sample of the same workload: sample_rows x n, U(-1,1)."""
     from oracle import ref_oracle as ro
     a = ro.uniform_matrix(sample_rows, n, seed=0)
-    md = ro.FP32_TC_COR if mode_name == "fp32_tc_cor" else ro.FP32_NOTC
+    md = ro.FP32_NOTC if mode_name == "fp32_notc" else ro.FP32_TC_COR   # the oracle models the two north-star modes
     ro.qr(a[:4096], md, False)
     t = time.time()
     st, q, r = ro.qr(a, md, False)
@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--m", type=int, default=1 << 20, help="rows per GPU")
     ap.add_argument("--n", type=int, default=64)
-    ap.add_argument("--mode", default="fp32_tc_cor", choices=["fp32_tc_cor", "fp32_notc"])
+    ap.add_argument("--mode", default="fp32_tc_cor", choices=["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor"])
     ap.add_argument("--reorth", type=int, default=0)
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 18)   # ~10-20 s of CPU work on the GPU box host
     ap.add_argument("--no-cpu-baseline", action="store_true")

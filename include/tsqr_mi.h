@@ -26,7 +26,7 @@ enum tsqr_mi_compute_mode {
 	TSQR_MI_FP16_TC_NOCOR = 1,
 	TSQR_MI_FP32_NOTC = 2,         /* supported: exact fp32 (VALU + v_mfma_f32_16x16x4_f32) */
 	TSQR_MI_FP32_TC_COR = 3,       /* supported: bf16 MFMA with 3-way split error correction */
-	TSQR_MI_FP32_TC_NOCOR = 4,
+	TSQR_MI_FP32_TC_NOCOR = 4,     /* supported: R as fp32_tc_cor; Q = A*inverse(R) on fp16 MFMA, one product, no correction */
 	TSQR_MI_MIXED_TC_COR_EMU = 5,
 	TSQR_MI_TF32_TC_COR = 6,       /* no xf32 MFMA on gfx950: unsupported */
 	TSQR_MI_TF32_TC_COR_EMU = 7,

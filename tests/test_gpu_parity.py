@@ -256,3 +256,24 @@ def test_dist_driver_single_rank(bq, oracle, torch_cuda, mode, use_gram, want_en
     q = d_q.cpu().numpy().T; r = d_r.cpu().numpy().T
     assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL
     assert np.abs(np.tril(r, -1)).max() == 0.0
+
+
+@pytest.mark.parametrize("m,n", [(128, 16), (20, 7), (4096, 64), (9211, 51), (65536, 64), (9000, 100)])
+@pytest.mark.parametrize("reorth", [False, True])
+def test_fp32_tc_nocor_mode(bq, oracle, torch_cuda, m, n, reorth):
+    """fp32_tc_nocor (reference src/tcqr32x16.cu:499-560: fp16 matrix-core products, no correction terms): fp16-level
+    accuracy by construction.  The oracle does not model this mode; the check is against fp64 LAPACK with the tolerance of
+    one fp16 rounding per operand (2^-11 = 4.9e-4): residual < 1e-3, ||Q^T Q - I||_F < 4e-3 * sqrt(n / 64 + 1),
+    sign-normalised R within 1e-3 -- and the R factor itself keeps fp32_tc_cor accuracy (it is computed the same way)."""
+    a = oracle.uniform_matrix(m, n, seed=21)
+    st, q, r = run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_tc_nocor, reorth, lda_pad=3, ldq_pad=1)
+    assert st == bq.success_factorization
+    assert np.isfinite(q).all() and np.isfinite(r).all() and np.abs(np.tril(r, -1)).max() == 0.0
+    res, orth = oracle.residual(a, q, r), oracle.orthogonality_fro(q)
+    assert 1e-6 < res < 1e-3, res                       # really the uncorrected half-precision product, not fp32_tc_cor
+    assert orth < 4e-3 * np.sqrt(n / 64 + 1), orth
+    q2, r2 = np.linalg.qr(a.astype(np.float64))
+    _, rn = oracle.sign_normalise(q, r)
+    _, r2n = oracle.sign_normalise(q2, r2)
+    tol = 1e-3 if (reorth or n > 64) else 5e-6           # one sweep, one panel: R comes from the corrected Gram path alone
+    assert np.abs(rn - r2n).max() / np.abs(r2n).max() < tol

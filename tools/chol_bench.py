@@ -23,3 +23,8 @@ for n in (4, 16, 32, 48, 64):
     ms = L.tsqr_selftest_chol_time(ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(st.data_ptr()),
                                    ctypes.c_void_p(sub.data_ptr()), n, NT, 50)
     print('n=%d: %.1f us  status %s' % (n, ms * 1e3, st[:1].tolist()))
+if hasattr(L, 'tsqr_selftest_chol_stamps'):
+    buf = (ctypes.c_longlong * 8)()
+    L.tsqr_selftest_chol_stamps(buf)
+    t = list(buf)
+    print('cycle stamps (100 MHz refclk or shader clock, see below):', [t[i] - t[0] for i in range(8)])

@@ -72,6 +72,12 @@ extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, c
 	return ms / reps;
 }
 
+#ifdef TSQR_CHOL_DBG
+extern "C" int tsqr_selftest_chol_stamps(long long* out) {
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tsqrmi::g_chol_dbg), sizeof(long long) * 8);
+}
+#endif
+
 // ---- copy kernel in the (c,q) chunk layout: the HBM ceiling of load_chunk + 16-B-per-lane stores ----
 template <int MODE>
 __global__ __launch_bounds__(256) void copy_cq_kernel(float* q, const float* a, size_t ld, size_t m, int nchunks, int cpw, int nwaves) {

@@ -21,6 +21,7 @@ namespace tsqrmi {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global access
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -732,6 +733,35 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ s
 	sub[(size_t)sidx * nelem + e] = (s0 + s1) + (s2 + s3);
 }
 
+// gram_reduce1_kernel: partials -> G in ONE launch (deterministic: fixed partition, fixed tree).  A workgroup owns 16
+// consecutive entries; thread (e = tid & 15, s = tid >> 4) sums the partials b = s, s+16, s+32, ... of entry e with four
+// independent accumulators, then the 16 s-sums of every entry are added through LDS in a fixed pairwise tree.
+__global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ gout, const double* __restrict__ part, int nparts, int nelem) {
+	__shared__ double red[16][17];
+	const int e = threadIdx.x & 15, s = threadIdx.x >> 4;
+	const int el = blockIdx.x * 16 + e;
+	double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+	if (el < nelem) {
+		int b = s;
+		for (; b + 48 < nparts; b += 64) {
+			s0 += part[(size_t)b * nelem + el];
+			s1 += part[(size_t)(b + 16) * nelem + el];
+			s2 += part[(size_t)(b + 32) * nelem + el];
+			s3 += part[(size_t)(b + 48) * nelem + el];
+		}
+		for (; b < nparts; b += 16) s0 += part[(size_t)b * nelem + el];
+	}
+	red[s][e] = (s0 + s1) + (s2 + s3);
+	__syncthreads();
+	if (s == 0 && el < nelem) {
+		double v[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) v[k] = red[k][e];
+		gout[el] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+		           (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+	}
+}
+
 // chol_kernel: sub-sums -> G (fp64) -> R = chol(G) and M = R^-T by the same row operations (forward elimination of
 // [R^T | I]), all in fp64.  Thread (w = wave, j = lane) owns column j and the rows i = w + 4 s of both G and M in
 // registers; step k: the wave owning row k scales it with 1/sqrt(pivot) (v_rsq_f64 + two Newton steps) and publishes
@@ -819,6 +849,12 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 
 // LOADG: functor e -> G tile entry e (accumulator order); host_status: optional device-visible alias of pinned host memory
 // that receives the three status words as well (the host then needs no copy operation to read them).
+#ifdef TSQR_CHOL_DBG
+__device__ long long g_chol_dbg[32];
+#define CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CHOL_STAMP(i) do { } while (0)
+#endif
 template <class LOADG>
 __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
@@ -830,6 +866,7 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	const int j = t & 63, w = t >> 6;
 	const int NP = 16 * NT;
 	// issue the loads of G first (one value per thread and tile), then initialise LDS while they are in flight
+	CHOL_STAMP(0);
 	double gv[10];
 	{
 		int idx = 0;
@@ -874,9 +911,11 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	const double dgj = Gs[j * 65 + j];
 	double s_acc = 0.0;
 	__syncthreads();
+	CHOL_STAMP(1);
 #pragma unroll 1
 	for (int kk = 0; kk < 4; kk++) {
 		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, z, pv, w, j, n, NP, kk, dgj, s_acc); });
+		CHOL_STAMP(2 + kk);
 #pragma unroll
 		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
 	}
@@ -909,10 +948,12 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 		}
 	}
 	// R out (fp32, exact zeros below the diagonal)
+	CHOL_STAMP(6);
 	for (int e = t; e < n * n; e += 256) {
 		const int i = e % n, jj = e / n;
 		r[(size_t)jj * ldr + i] = (i <= jj) ? Rf[i * 65 + jj] : 0.0f;
 	}
+	CHOL_STAMP(7);
 }
 
 __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
@@ -1298,6 +1339,8 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 //   * wave w multiplies rows [w*ROWS/4, (w+1)*ROWS/4): A operand = 4-byte LDS reads along k, products as in apply_kernel,
 //     the result tile overwrites the wave's own rows of As in place;
 //   * after a barrier the block leaves through the same linear mapping (UPD: + the C input, loaded linearly as well).
+// ENGINE 2 (fp32_tc_nocor, reference src/tcqr32x16.cu:499-560's mode): v_mfma_f32_16x16x32_f16 on fp16-rounded operands, no
+// correction terms (range and precision of fp16, like the reference's mode).
 // ApplyArgs: nchunks = number of row blocks, nwaves = number of workgroups, cpw unused.
 // ---------------------------------------------------------------------------------------------
 template <int ENGINE, int NT, bool UPD, int ROWS>
@@ -1322,6 +1365,14 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 		for (int idx = threadIdx.x; idx < NP * NP; idx += 256) {
 			const int k = idx % NP, j = idx / NP;
 			Zs[k * ZS + j] = a.z[(size_t)j * NP + k];
+		}
+	} else if constexpr (ENGINE == 2) {
+		// Zh[kt][ct][lane][8] : B operand of v_mfma_f32_16x16x32_f16, one fp16 image (no correction terms)
+		_Float16* Zh = reinterpret_cast<_Float16*>(zbase);
+		for (int idx = threadIdx.x; idx < KT * NT * 64 * 8; idx += 256) {
+			const int jj = idx & 7, l = (idx >> 3) & 63, ct = (idx >> 9) % NT, kt = (idx >> 9) / NT;
+			const int k = 32 * kt + 8 * (l >> 4) + jj, j = 16 * ct + (l & 15);
+			Zh[((kt * NT + ct) * 64 + l) * 8 + jj] = (_Float16)((k < NP) ? a.z[(size_t)j * NP + k] : 0.0f);
 		}
 	} else {
 		unsigned short* Zb = reinterpret_cast<unsigned short*>(zbase);
@@ -1400,6 +1451,26 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 						}
 					}
 				}
+			} else if constexpr (ENGINE == 2) {
+				// fp32_tc_nocor: both operands rounded to fp16 (round to nearest even), ONE product per block, fp32 accumulation
+				const _Float16* Zh = reinterpret_cast<const _Float16*>(zbase);
+				f16x8 ah[KT];
+#pragma unroll
+				for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+					for (int e = 0; e < 8; e++) {
+						const int k0 = 32 * kt + 8 * q + e;
+						ah[kt][e] = (_Float16)((k0 < NP) ? As[k0 * RS + ((rb + c) ^ swz(k0))] : 0.0f);
+					}
+#pragma unroll
+				for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+					for (int ct = 0; ct < NT; ct++) {
+						if (UPD || 32 * kt <= 16 * ct + 15) {         // triangular Z: block (kt, ct) is zero when all its k > all its j
+							const f16x8 bh = *reinterpret_cast<const f16x8*>(&Zh[((kt * NT + ct) * 64 + lane) * 8]);
+							acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kt], bh, acc[ct], 0, 0, 0);
+						}
+					}
 			} else {
 				const unsigned short* Zb = reinterpret_cast<const unsigned short*>(zbase);
 				constexpr int PS = KT * NT * 512;

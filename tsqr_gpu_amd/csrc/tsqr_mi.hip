@@ -48,6 +48,7 @@ int g_fused = env_int("TSQR_MI_FUSED", 0);            // 1: second reduction sta
 // dev = device-visible alias of h_wl (null when it is not pinned host memory: then a 4-byte copy is enqueued as before).
 struct HostSig { unsigned* host = nullptr; unsigned* dev = nullptr; };
 HostSig g_hsig;
+int g_reduce1 = env_int("TSQR_MI_REDUCE1", 1);         // partials -> G in one launch (gram_reduce1_kernel) instead of two
 int g_gram_impl = env_int("TSQR_MI_GRAM_IMPL", 0);     // bf16 Gram: 0 per-wave chunks, 1 workgroup blocks of 128 rows, 2 of 256 rows
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
@@ -266,9 +267,13 @@ int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float*
 	double* sub = reinterpret_cast<double*>(wq + L.gsub);
 	{
 		ProfScope ps(KC_CHOL, st);
-		hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
-		                   sub, a.part, nparts, nelem, nsplit);
-		hipLaunchKernelGGL(tsqrmi::gram_reduce2_kernel, dim3((nelem + 255) / 256), dim3(256), 0, st, gsum, sub, nelem, nsplit);
+		if (g_reduce1) {
+			hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, st, gsum, a.part, nparts, nelem);
+		} else {
+			hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
+			                   sub, a.part, nparts, nelem, nsplit);
+			hipLaunchKernelGGL(tsqrmi::gram_reduce2_kernel, dim3((nelem + 255) / 256), dim3(256), 0, st, gsum, sub, nelem, nsplit);
+		}
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -343,7 +348,8 @@ template <int E, int NT, bool UPD = false> int launch_apply(const tsqrmi::ApplyA
 // workgroup-cooperative variant (apply_wg_kernel): args.nchunks = row blocks of ROWS, args.nwaves = workgroups
 template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyArgs a, hipStream_t st) {
 	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
-	const size_t lds = sizeof(float) * NP * (ROWS + 4) + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)3 * KT * NT * 512 * 2);
+	const size_t lds = sizeof(float) * NP * (ROWS + 4) +
+	                   (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)(E == 2 ? 1 : 3) * KT * NT * 512 * 2);
 	static bool attr_done = false;
 	if (!attr_done) {
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>),
@@ -358,9 +364,13 @@ template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyAr
 	return 0;
 }
 template <int E, int NT, bool UPD> int launch_apply_any(const tsqrmi::ApplyArgs& a, hipStream_t st) {
-	if (g_apply_impl == 1) return launch_apply_wg<E, NT, UPD, 128>(a, st);
-	if (g_apply_impl == 2) return launch_apply_wg<E, NT, UPD, 256>(a, st);
-	return launch_apply<E, NT, UPD>(a, st);
+	if constexpr (E == 2) {                              // fp32_tc_nocor exists in the workgroup kernel only
+		return launch_apply_wg<E, NT, UPD, 128>(a, st);
+	} else {
+		if (g_apply_impl == 1) return launch_apply_wg<E, NT, UPD, 128>(a, st);
+		if (g_apply_impl == 2) return launch_apply_wg<E, NT, UPD, 256>(a, st);
+		return launch_apply<E, NT, UPD>(a, st);
+	}
 }
 template <int E> int dispatch_apply_nt(int NT, const tsqrmi::ApplyArgs& a, hipStream_t st) {
 	switch (NT) {
@@ -391,7 +401,7 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
 	int rc;
 	{
 		ProfScope ps(KC_APPLY, st);
-		rc = (engine == 0) ? dispatch_apply_nt<0>(NT, aa, st) : dispatch_apply_nt<1>(NT, aa, st);
+		rc = (engine == 0) ? dispatch_apply_nt<0>(NT, aa, st) : (engine == 1 ? dispatch_apply_nt<1>(NT, aa, st) : dispatch_apply_nt<2>(NT, aa, st));
 	}
 	if (rc) return rc;
 	HIPCHK(hipGetLastError());
@@ -401,8 +411,7 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
 // Is h_wl pinned host memory the device can write?  (mtk::qr::buffer allocates it with hipHostMalloc; anything else
 // falls back to copy + stream sync.)  The answer is cached per pointer.
 void resolve_host_sig(unsigned* h_wl) {
-	if (h_wl == g_hsig.host) return;
-	g_hsig.host = h_wl; g_hsig.dev = nullptr;
+	g_hsig.host = h_wl; g_hsig.dev = nullptr;            // queried on every call (sub-microsecond): the caller may have re-allocated
 	if (!h_wl || !g_host_status) return;
 	hipPointerAttribute_t at{};
 	if (hipPointerGetAttributes(&at, h_wl) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -434,6 +443,7 @@ int signal_and_wait(hipStream_t st) {
 int engine_of(int mode) {
 	if (mode == TSQR_MI_FP32_NOTC) return 0;
 	if (mode == TSQR_MI_FP32_TC_COR) return 1;
+	if (mode == TSQR_MI_FP32_TC_NOCOR) return 2;         // R factor as fp32_tc_cor, Q = A * inverse(R) with fp16 operands and no correction
 	return -1;
 }
 
@@ -525,7 +535,8 @@ int sweep(int engine, int r_engine, bool check_now, float* q, size_t ldq, float*
 			ua.cpw = (int)std::max<size_t>(1, cdiv(nch, (size_t)g_apply_waves));
 			ua.nchunks = (int)nch;
 			ua.nwaves = (int)cdiv(nch, (size_t)ua.cpw);
-			const int rc2 = (engine == 0) ? launch_apply_any<0, 4, true>(ua, st) : launch_apply_any<1, 4, true>(ua, st);
+			const int rc2 = (engine == 0) ? launch_apply_any<0, 4, true>(ua, st)
+			                              : (engine == 1 ? launch_apply_any<1, 4, true>(ua, st) : launch_apply_any<2, 4, true>(ua, st));
 			if (rc2) return rc2;
 			HIPCHK(hipGetLastError());
 		}
@@ -626,7 +637,7 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 
 	// R-factor engine levels: 2 bf16-split Gram (memory-bound), 1 fp64 Gram, 0 Householder TSQR.  Deferred mode runs a level
 	// speculatively and steps down when chol_kernel rejected it; with check_now panel_qr escalates per panel by itself.
-	const int first_level = !use_gram ? 0 : ((mode == TSQR_MI_FP32_TC_COR || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1));
+	const int first_level = !use_gram ? 0 : ((mode != TSQR_MI_FP32_NOTC || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1));
 	for (int level = first_level; level >= 0; level--) {
 		int rc = sweep(engine, level, check_now, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
 		if (rc) return rc;
@@ -785,7 +796,7 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 	float* rl = wq + L.r2;                               // local R, n x n packed (ld n)
 	const float* src = a; size_t ld_src = lda;
 	const bool use_gram = (g_policy == 2) || (g_policy == 0);
-	const int first_level = (mode == TSQR_MI_FP32_TC_COR || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1);
+	const int first_level = (mode != TSQR_MI_FP32_NOTC || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1);
 	nccl_allreduce_t allreduce = use_gram ? resolve_allreduce() : nullptr;
 	for (int it = 0; it < (reorth ? 2 : 1); it++) {
 		int rc;
