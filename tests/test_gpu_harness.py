@@ -113,3 +113,18 @@ def test_csv_drivers_schema_and_values(env):
     assert lines[0] == "m,n,cond,type,compute_mode,reorthogonalization,residual,residual_deviation,orthogonality,orthogonality_deviation"
     assert lines[1].startswith("4096,64,10000,float,fp32_tc_cor,1,")
     assert rows[0][3] < 5e-6 and rows[0][5] < 2e-6         # BCGS2 restores orthogonality at cond 1e4
+
+
+def test_rocsolver_comparison_columns(env):
+    """The vendor-library lines of the reference's sweep (src/test.cu:366-593, cuSOLVER there, rocSOLVER here)."""
+    torch, bq, harness, oracle = env
+    out = io.StringIO()
+    rows = harness.rocsolver_accuracy([(4096, 64, 1.0)], C=2, dtype=torch.float32, out=out)
+    rows += harness.rocsolver_accuracy([(4096, 64, 1.0)], C=2, dtype=torch.float64, out=out, head=False)
+    lines = out.getvalue().strip().split("\n")
+    assert lines[1].startswith("4096,64,1,float,rocsolver,0,") and lines[2].startswith("4096,64,1,double,rocsolver,0,")
+    assert rows[0][2] < 2e-6 and rows[0][4] < 2e-6            # fp32 Householder
+    assert rows[1][2] < 1e-14 and rows[1][4] < 1e-14          # fp64
+    out = io.StringIO()
+    rows = harness.rocsolver_speed([(1 << 16, 64, 1.0)], C=2, out=out)
+    assert out.getvalue().split("\n")[1].startswith("65536,64,1,float,rocsolver,0,") and rows[0][2] > 0

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--what", default="accuracy,speed,cond")
     args = ap.parse_args()
     what = args.what.split(",")
-    modes = [bq.compute_mode.fp32_notc, bq.compute_mode.fp32_tc_cor]
+    modes = [bq.compute_mode.fp32_notc, bq.compute_mode.fp32_tc_nocor, bq.compute_mode.fp32_tc_cor]
     if args.full:
         C = args.count or 16
         sizes = [(1 << m, 1 << n, 1.0) for m in range(10, 16) for n in range(10, m + 1)]
@@ -35,10 +35,14 @@ def main():
         for reorth in (False, True):
             for mode in modes:
                 harness.accuracy(sizes, C, mode, reorth)
+        for dt in (torch.float32, torch.float64):               # the place cusolver_accuracy<float/double> has in src/main.cu:35-36
+            harness.rocsolver_accuracy(sizes, C, dt)
     if "speed" in what:
         for reorth in (False, True):
             for mode in modes:
                 harness.speed(sizes, C, mode, reorth)
+        for dt in (torch.float32, torch.float64):
+            harness.rocsolver_speed(sizes, C, dt)
     if "cond" in what:
         print("# condition number test")
         for reorth in (False, True):

@@ -223,3 +223,98 @@ def accuracy_cond(matrix_config_list, C=8, mode=bq.compute_mode.fp32_tc_cor, reo
               file=out, flush=True)
         rows.append((m, n, cond, rm, rv, om, ov))
     return rows
+
+
+# ---- vendor-library comparison: rocSOLVER geqrf + orgqr in the place cuSOLVER has in the reference (src/test.cu:366-593) ----
+class _RocSolver:
+    """ctypes binding of the four rocSOLVER entry points the comparison needs (harness only, not the hot path)."""
+    _inst = None
+
+    def __init__(self):
+        self.rb = ctypes.CDLL("librocblas.so", mode=ctypes.RTLD_GLOBAL)
+        self.rs = ctypes.CDLL("librocsolver.so")
+        self.handle = ctypes.c_void_p()
+        if self.rb.rocblas_create_handle(ctypes.byref(self.handle)) != 0:
+            raise RuntimeError("rocblas_create_handle failed")
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        for name in ("rocsolver_sgeqrf", "rocsolver_dgeqrf"):
+            getattr(self.rs, name).argtypes = [vp, ci, ci, vp, ci, vp]
+        for name in ("rocsolver_sorgqr", "rocsolver_dorgqr"):
+            getattr(self.rs, name).argtypes = [vp, ci, ci, ci, vp, ci, vp]
+        self.rb.rocblas_set_stream.argtypes = [vp, vp]
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+    def qr(self, a, m, n):
+        """a: (n, m) tensor = column-major m x n, float32 or float64; returns (Q as (n, m) tensor, R as (n, n) column-major)."""
+        self.rb.rocblas_set_stream(self.handle, torch.cuda.current_stream().cuda_stream)
+        w = a.clone()
+        tau = torch.empty(n, dtype=a.dtype, device=a.device)
+        p = "s" if a.dtype == torch.float32 else "d"
+        st = getattr(self.rs, "rocsolver_%sgeqrf" % p)(self.handle, m, n, w.data_ptr(), m, tau.data_ptr())
+        if st != 0:
+            raise RuntimeError("rocsolver geqrf -> %d" % st)
+        r = torch.triu(w[:, :n].T).T.contiguous()            # column-major R: entry (i, j) at r[j, i], i <= j
+        st = getattr(self.rs, "rocsolver_%sorgqr" % p)(self.handle, m, n, n, w.data_ptr(), m, tau.data_ptr())
+        if st != 0:
+            raise RuntimeError("rocsolver orgqr -> %d" % st)
+        return w, r
+
+
+def _metrics_torch(q, r, a, m, n):
+    """residual and the reference's orthogonality metric in fp64 with torch (vendor comparison only; any dtype)."""
+    q64, r64, a64 = q.double(), r.double(), a.double()
+    res = torch.sqrt(((r64 @ q64) - a64).pow(2).sum() / a64.pow(2).sum()).item()       # (QR)^T = R^T Q^T in this storage
+    e = q64 @ q64.T - torch.eye(n, dtype=torch.float64, device=q.device)
+    return res, math.sqrt(e.pow(2).sum().item() / n)
+
+
+def rocsolver_accuracy(matrix_config_list, C=16, dtype=torch.float32, out=sys.stdout, seed=0, head=True):
+    """src/test.cu:366-491 (cusolver_accuracy<T>) with rocSOLVER; compute_mode column says 'rocsolver'."""
+    if head:
+        print(ACCURACY_HEAD, file=out)
+    rows = []
+    rs = _RocSolver.get()
+    for (m, n, rr) in matrix_config_list:
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed)
+        res, orth = [], []
+        for _ in range(C):
+            a = ((torch.rand(n, m, generator=gen, device="cuda", dtype=torch.float32) * 2 - 1) * rr).to(dtype)
+            q, r = rs.qr(a, m, n)
+            x, y = _metrics_torch(q, r, a, m, n)
+            res.append(x)
+            orth.append(y)
+        (rm, rv), (om, ov) = _mean_var(res), _mean_var(orth)
+        print("%d,%d,%g,%s,rocsolver,0,%e,%e,%e,%e" % (m, n, rr, "float" if dtype == torch.float32 else "double", rm, rv, om, ov),
+              file=out, flush=True)
+        rows.append((m, n, rm, rv, om, ov))
+    return rows
+
+
+def rocsolver_speed(matrix_config_list, C=16, dtype=torch.float32, out=sys.stdout, seed=0, head=True):
+    """src/test.cu:496-593 (cusolver_speed<T>): geqrf + orgqr, one warm-up, wall clock over C blocking repetitions."""
+    if head:
+        print(SPEED_HEAD, file=out)
+    rows = []
+    rs = _RocSolver.get()
+    for (m, n, rr) in matrix_config_list:
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed)
+        a = ((torch.rand(n, m, generator=gen, device="cuda", dtype=torch.float32) * 2 - 1) * rr).to(dtype)
+        rs.qr(a, m, n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(C):
+            rs.qr(a, m, n)
+            torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / C
+        tf = reference_flop_formula(m, n) / el / 1024.0 ** 4
+        print("%d,%d,%g,%s,rocsolver,0,%e,%e,%d" % (m, n, rr, "float" if dtype == torch.float32 else "double", el, tf, 0),
+              file=out, flush=True)
+        rows.append((m, n, el, tf))
+    return rows
