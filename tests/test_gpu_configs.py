@@ -1,0 +1,86 @@
+"""BASELINE.json configs C1-C5 at their full sizes, checked through size-independent properties evaluated on the device in
+fp64 (tsqr_mi_validate_f32): residual, ||Q^T Q - I||_F, R upper triangular.  C2 lives in test_gpu_parity.py::test_full_size_properties;
+C4's 8-GPU partitioning is covered by the gloo tests (CPU) and by the row-partitioned driver on one rank here."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from tsqr_gpu_amd import blockqr as bq, harness
+    from oracle import ref_oracle as oracle
+    assert torch.cuda.is_available()
+    return torch, bq, harness, oracle
+
+
+def test_c1_128x16_against_host_lapack(env):
+    """C1: M=128, N=16 -- host LAPACK sgeqrf/sorgqr is the reference (seeds the residual / orthogonality plumbing)."""
+    torch, bq, harness, oracle = env
+    from scipy.linalg import lapack
+    m, n = 128, 16
+    a = oracle.uniform_matrix(m, n, seed=0)
+    qr_, tau, _, info = lapack.sgeqrf(np.asfortranarray(a))
+    assert info == 0
+    q_l, _, info = lapack.sorgqr(qr_[:, :n].copy(order="F"), tau)
+    r_l = np.triu(qr_[:n, :n])
+    ql, rl = oracle.sign_normalise(q_l, r_l)
+    assert oracle.residual(a, q_l, r_l) < 5e-7 and oracle.orthogonality_fro(q_l) < 2e-6      # the plumbing itself
+    for mode in (bq.compute_mode.fp32_notc, bq.compute_mode.fp32_tc_cor):
+        d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+        st, d_q, d_r = harness.qr(d_a, m, n, mode, False)
+        assert st == 0
+        q, r = d_q.cpu().numpy().T, d_r.cpu().numpy().T
+        qn, rn = oracle.sign_normalise(q, r)
+        assert np.abs(rn - rl).max() / np.abs(rl).max() < 5e-6 and np.abs(qn - ql).max() < 5e-6
+        assert harness.residual(d_q, d_r, d_a, m, n) < 5e-7 and harness.orthogonality_fro(d_q, m, n) < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+def test_c3_2pow20_x_128(env, mode):
+    """C3: M=2^20, N=128 (two 64-wide panels coupled by block modified Gram-Schmidt on the matrix cores)."""
+    torch, bq, harness, oracle = env
+    m, n = 1 << 20, 128
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    d_a = torch.rand(n, m, generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    d_a0 = d_a.clone()                                                 # a is clobbered for n > 64
+    st, d_q, d_r = harness.qr(d_a, m, n, bq.compute_mode[mode], False)
+    assert st == 0
+    assert harness.orthogonality_fro(d_q, m, n) < 1e-5
+    assert harness.residual(d_q, d_r, d_a0, m, n) < 5e-7
+    assert torch.tril(d_r.T, -1).abs().max().item() == 0.0
+
+
+def test_c4_2pow23_x_64_row_partitioned_driver_one_rank(env):
+    """C4's global shape (2^23 x 64) through the row-partitioned driver (one rank: no collective, same kernels and staging)."""
+    torch, bq, harness, oracle = env
+    from tsqr_gpu_amd import dist as tdist
+    m, n = 1 << 23, 64
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    d_a = torch.rand(n, m, generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+    eng = tdist.HipEngine(bq.compute_mode.fp32_tc_cor, m, n, 1)
+    assert tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng) == 0
+    torch.cuda.synchronize()
+    assert eng.last_engine == 3
+    assert harness.orthogonality_fro(d_q, m, n) < 1e-5
+    assert harness.residual(d_q, d_r, d_a, m, n) < 5e-7
+
+
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+def test_c5_latms_cond_1e8_reorth(env, mode):
+    """C5: latms-generated 2^20 x 64 with cond 1e8 (numerically rank-deficient in fp32), Reorthogonalize = true."""
+    torch, bq, harness, oracle = env
+    m, n = 1 << 20, 64
+    s = torch.logspace(0, -8, n, dtype=torch.float64)                  # geometric spectrum, cond = 1e8 (SURVEY 8d's second case)
+    d_a = harness.latms(m, n, n, s, seed=5)
+    st, d_q, d_r = harness.qr(d_a, m, n, bq.compute_mode[mode], True)
+    assert st == 0
+    assert bq.last_engine() in (1, 2)                                  # never the bf16-split level on such input
+    assert harness.orthogonality_fro(d_q, m, n) < 1e-5                 # O(eps) after the second sweep
+    assert harness.residual(d_q, d_r, d_a, m, n) < 2e-6
+    assert torch.tril(d_r.T, -1).abs().max().item() == 0.0
