@@ -1360,6 +1360,38 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 	const int c = lane & 15, q = lane >> 4;
 	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
 
+	const int nblk = a.nchunks, nwg = a.nwaves;
+	auto blk = [&](int i) {
+#ifndef TSQR_APPLY_FORWARD
+		return nblk - 1 - i;                             // last-touched rows of A first (Infinity-Cache reuse after the R pass)
+#else
+		return i;
+#endif
+	};
+	auto swz = [](int col) { return ((col >> 3) & 1) << 4; };
+	auto load_block = [&](f32x4 (&v)[NI], const float* base, size_t ld, int ncols, int b) {
+		const size_t row = (size_t)b * ROWS + lrow;
+#pragma unroll
+		for (int k = 0; k < NI; k++) {
+			const int col = (wv + 4 * k) * CPI + lcol;
+			v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+			if (col < ncols) {
+				const float* src = base + (size_t)col * ld + row;
+				if (row + 3 < a.m) v[k] = *reinterpret_cast<const f32x4u*>(src);
+				else {
+#pragma unroll
+					for (int i = 0; i < 4; i++)
+						if (row + i < a.m) v[k][i] = src[i];
+				}
+			}
+		}
+	};
+
+	// the first block's loads are issued before Z is staged: their HBM latency overlaps the staging work
+	f32x4 v[NI];
+	int bi = blockIdx.x;
+	if (bi < nblk) load_block(v, a.a, a.lda, a.n, blk(bi));
+
 	if constexpr (ENGINE == 0) {
 		float* Zs = reinterpret_cast<float*>(zbase);
 		for (int idx = threadIdx.x; idx < NP * NP; idx += 256) {
@@ -1389,36 +1421,6 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 		}
 	}
 
-	const int nblk = a.nchunks, nwg = a.nwaves;
-	auto blk = [&](int i) {
-#ifndef TSQR_APPLY_FORWARD
-		return nblk - 1 - i;                             // last-touched rows of A first (Infinity-Cache reuse after the R pass)
-#else
-		return i;
-#endif
-	};
-	auto swz = [](int col) { return ((col >> 3) & 1) << 4; };
-	auto load_block = [&](f32x4 (&v)[NI], const float* base, size_t ld, int ncols, int b) {
-		const size_t row = (size_t)b * ROWS + lrow;
-#pragma unroll
-		for (int k = 0; k < NI; k++) {
-			const int col = (wv + 4 * k) * CPI + lcol;
-			v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-			if (col < ncols) {
-				const float* src = base + (size_t)col * ld + row;
-				if (row + 3 < a.m) v[k] = *reinterpret_cast<const f32x4u*>(src);
-				else {
-#pragma unroll
-					for (int i = 0; i < 4; i++)
-						if (row + i < a.m) v[k][i] = src[i];
-				}
-			}
-		}
-	};
-
-	f32x4 v[NI];
-	int bi = blockIdx.x;
-	if (bi < nblk) load_block(v, a.a, a.lda, a.n, blk(bi));
 	for (; bi < nblk; bi += nwg) {
 		const int b = blk(bi);
 #pragma unroll
