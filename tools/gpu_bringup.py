@@ -31,7 +31,7 @@ def run(a, mode, reorth, lda_pad=0):
 
 cases = [(64, 16), (128, 16), (100, 7), (33, 16), (20, 7), (64, 64), (200, 64), (4096, 64), (9211, 51), (4096, 32),
          (65536, 64), (1 << 20, 64), (4096, 128), (9000, 100), (1 << 17, 128)]
-for (m, n) in cases[:0]:
+for (m, n) in cases:
     a = ro.uniform_matrix(m, n, seed=1)
     for mode in (bq.compute_mode.fp32_notc, bq.compute_mode.fp32_tc_cor):
         for reorth in (False, True):

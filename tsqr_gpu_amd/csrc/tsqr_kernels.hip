@@ -962,25 +962,6 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 	chol_body(r, ldr, z, status, host_status, [&](int e) { return gsum[e]; }, n, NT, f32_layout, min_ratio, max_scond);
 }
 
-// chol_sub_kernel: chol_kernel fused with the second reduction stage -- G entries are formed from the nsplit sub-sums
-// (same fixed order as gram_reduce2_kernel, so R is bitwise the same) while they are loaded; G is also written to gsum.
-__global__ __launch_bounds__(256) void chol_sub_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
-                                                       unsigned* __restrict__ host_status, const double* __restrict__ sub,
-                                                       double* __restrict__ gsum, int nelem, int nsplit, int n, int NT, int f32_layout,
-                                                       float min_ratio, float max_scond) {
-	chol_body(r, ldr, z, status, host_status,
-	          [&](int el) {
-		          double v[16];
-#pragma unroll
-		          for (int s2 = 0; s2 < 16; s2++) v[s2] = (s2 < nsplit) ? sub[(size_t)s2 * nelem + el] : 0.0;
-		          const double g = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
-		                           (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
-		          gsum[el] = g;
-		          return g;
-	          },
-	          n, NT, f32_layout, min_ratio, max_scond);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Panel coupling for n > 64 (block modified Gram-Schmidt between 64-column panels; replaces the two cuBLAS GEMMs of
 // reference src/blockqr.cu:92-116):

@@ -42,7 +42,6 @@ float g_bf16_max_scond = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);   // accep
 int g_debug = env_int("TSQR_MI_DEBUG", 0);
 int g_host_status = env_int("TSQR_MI_HOST_STATUS", 1);   // Cholesky status words written straight into the pinned h_wl
 int g_host_flag = env_int("TSQR_MI_HOST_FLAG", 1);       // end of call: spin on a pinned flag word instead of hipStreamSynchronize
-int g_fused = env_int("TSQR_MI_FUSED", 0);            // 1: second reduction stage fused into the Cholesky kernel, status words written to pinned host memory
 // The Cholesky kernel also writes its status words (status, min pivot ratio, scaled cond) straight into the caller's pinned
 // h_wl (mtk::qr::buffer::hl) so that the host needs no copy operation to read them after the stream sync.
 // dev = device-visible alias of h_wl (null when it is not pinned host memory: then a 4-byte copy is enqueued as before).
@@ -297,36 +296,6 @@ int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t n
 int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size_t m, size_t n,
            float* wq, float* wr, const WqLayout& L, bool bf16, hipStream_t st) {
 	double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 16 * 256;
-	if (g_fused) {                                       // two launches after the Gram kernel: sub-sums, then reduce2 + Cholesky in one
-		const GramPlan g = gram_plan(m, n);
-		const int NT = (int)(np_of(n) / 16);
-		tsqrmi::GramArgs a{};
-		a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
-		a.part = reinterpret_cast<double*>(wr);
-		int nparts = g.nblocks;
-		{
-			ProfScope ps(KC_GRAM, st);
-			switch (NT) {
-				case 1: nparts = launch_gram<1>(a, g.nblocks, bf16, st); break;
-				case 2: nparts = launch_gram<2>(a, g.nblocks, bf16, st); break;
-				case 3: nparts = launch_gram<3>(a, g.nblocks, bf16, st); break;
-				default: nparts = launch_gram<4>(a, g.nblocks, bf16, st); break;
-			}
-		}
-		const int nelem = g.ntri * 256;
-		const int nsplit = std::min(GRAM_NSPLIT, nparts);
-		double* sub = reinterpret_cast<double*>(wq + L.gsub);
-		{
-			ProfScope ps(KC_CHOL, st);
-			hipLaunchKernelGGL(tsqrmi::gram_reduce_kernel, dim3((nelem + 255) / 256, nsplit), dim3(256), 0, st,
-			                   sub, a.part, nparts, nelem, nsplit);
-			hipLaunchKernelGGL(tsqrmi::chol_sub_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
-			                   reinterpret_cast<unsigned*>(wq + L.status), g_hsig.dev, sub, gsum, nelem, nsplit, (int)n, NT,
-			                   bf16 ? 1 : 0, bf16 ? 0.03125f : 9.094947017729282e-13f, bf16 ? g_bf16_max_scond : INFINITY);
-		}
-		HIPCHK(hipGetLastError());
-		return 0;
-	}
 	const int rc = gram_g(gsum, src, ld, m, n, wq, wr, L, bf16, st);
 	if (rc) return rc;
 	return chol_from_g(r, ldr, z_buf, gsum, n, wq, L, bf16, st, g_hsig.dev);
