@@ -806,7 +806,9 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
 			double y = __builtin_amdgcn_rsq(piv);
 			y = y * (1.5 - 0.5 * piv * y * y);
+#if !defined(TSQR_CHOL_NEWTON) || TSQR_CHOL_NEWTON >= 2
 			y = y * (1.5 - 0.5 * piv * y * y);
+#endif
 			const bool live = K < n;
 			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
 			const double mk = live ? mm[u] * y : 0.0;
@@ -876,7 +878,8 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 				else gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = 0.0;
 			}
 	}
-	for (int i = t; i < 64 * 65; i += 256) { Gs[i] = 0.0; Rf[i] = 0.0f; }
+	if (NT < 4)                                          // with all ten tiles present every entry of Gs is written below
+		for (int i = t; i < 64 * 65; i += 256) Gs[i] = 0.0;  // (Rf needs no initialisation: rows K < n are written in full)
 	for (int e = n * NP + t; e < NP * NP; e += 256) z[e] = 0.0f;          // padding rows of Z
 	__syncthreads();
 	{
@@ -949,9 +952,10 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	}
 	// R out (fp32, exact zeros below the diagonal)
 	CHOL_STAMP(6);
-	for (int e = t; e < n * n; e += 256) {
-		const int i = e % n, jj = e / n;
-		r[(size_t)jj * ldr + i] = (i <= jj) ? Rf[i * 65 + jj] : 0.0f;
+	{
+		const int i = t & 63;
+		if (i < n)
+			for (int jj = t >> 6; jj < n; jj += 4) r[(size_t)jj * ldr + i] = (i <= jj) ? Rf[i * 65 + jj] : 0.0f;
 	}
 	CHOL_STAMP(7);
 }
