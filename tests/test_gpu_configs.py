@@ -84,3 +84,51 @@ def test_c5_latms_cond_1e8_reorth(env, mode):
     assert harness.orthogonality_fro(d_q, m, n) < 1e-5                 # O(eps) after the second sweep
     assert harness.residual(d_q, d_r, d_a, m, n) < 2e-6
     assert torch.tril(d_r.T, -1).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("mode,policy,want", [("fp32_tc_cor", 0, 3), ("fp32_notc", 0, 1), ("fp32_tc_cor", 1, 0)])
+@pytest.mark.parametrize("reorth", [0, 1])
+def test_cpp_dist_entry_point_over_rccl_single_rank(env, mode, policy, want, reorth):
+    """tsqr_mi_qr_f32_dist (the one-call C++ driver over an ncclComm_t) on a one-rank RCCL communicator created through
+    ctypes: exercises the dlopen'ed ncclAllReduce / ncclAllGather calls, the speculative apply and the Householder stack."""
+    import ctypes
+    torch, bq, harness, oracle = env
+    try:
+        rccl = ctypes.CDLL("librccl.so")
+    except OSError:
+        pytest.skip("librccl.so not loadable by name")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_byte * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        m, n = 50000, 64
+        a = oracle.uniform_matrix(m, n, seed=17)
+        d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+        d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+        wq = torch.empty(bq.get_working_q_size(m, n), device="cuda"); wr = torch.empty(bq.get_working_r_size(m, n), device="cuda")
+        gather = torch.empty(n * n, device="cuda")
+        bq.set_policy(policy)
+        try:
+            st = bq.lib().tsqr_mi_qr_f32_dist(int(bq.compute_mode[mode]), reorth, d_q.data_ptr(), m, d_r.data_ptr(), n,
+                                              d_a.data_ptr(), m, m, n, wq.data_ptr(), wr.data_ptr(), gather.data_ptr(),
+                                              comm, 1, torch.cuda.current_stream().cuda_stream)
+        finally:
+            bq.set_policy(bq.POLICY_AUTO)
+        torch.cuda.synchronize()
+        assert st == 0, bq.last_error()
+        assert harness.orthogonality_fro(d_q, m, n) < 5e-6 and harness.residual(d_q, d_r, d_a, m, n) < 5e-7
+        assert torch.tril(d_r.T, -1).abs().max().item() == 0.0
+        q2, r2 = np.linalg.qr(a.astype(np.float64))
+        _, rn = oracle.sign_normalise(d_q.cpu().numpy().T, d_r.cpu().numpy().T)
+        _, r2n = oracle.sign_normalise(q2, r2)
+        assert np.abs(rn - r2n).max() / np.abs(r2n).max() < 5e-6
+        del want
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
