@@ -340,7 +340,11 @@ __global__ __launch_bounds__(256) void copy_wg_kernel(float* q, const float* a, 
 			for (int k = 0; k < NI; k++) {
 				const int col = (wv + 4 * k) * CPI + lcol;
 				const tsqrmi::f32x4 x = *reinterpret_cast<const tsqrmi::f32x4*>(&As[col * RS + lrow]);
+#ifdef TSQR_SKELETON_CACHED_STORE
 				*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + lrow) = x;
+#else
+				__builtin_nontemporal_store(x, reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + lrow));
+#endif
 			}
 		}
 		__syncthreads();
@@ -396,4 +400,48 @@ extern "C" double tsqr_selftest_launch_cost(unsigned* dev_word, unsigned* pinned
 	const auto t1 = std::chrono::steady_clock::now();
 	(void)hipDeviceSynchronize();
 	return std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
+}
+
+
+// ---- one-directional limits of the workgroup skeleton: MODE 0 copy (nontemporal stores), 1 load only, 2 store only (nontemporal) ----
+template <int MODE>
+__global__ __launch_bounds__(256) void stream_wg_kernel(float* q, const float* a, size_t ld, size_t m, int nblocks, int nwg) {
+	constexpr int ROWS = 128, NP = 64;
+	constexpr int LPC = ROWS / 4, CPI = 64 / LPC, NI = NP / (4 * CPI);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
+	tsqrmi::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+	for (int b = blockIdx.x; b < nblocks; b += nwg) {
+		tsqrmi::f32x4 v[NI];
+#pragma unroll
+		for (int k = 0; k < NI; k++) {
+			const size_t off = (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)b * ROWS + lrow;
+			if (MODE != 2) v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + off);
+			else v[k] = tsqrmi::f32x4{(float)b, (float)k, 1.f, 2.f};
+		}
+#pragma unroll
+		for (int k = 0; k < NI; k++) {
+			const size_t off = (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)b * ROWS + lrow;
+			if (MODE != 1) __builtin_nontemporal_store(v[k], reinterpret_cast<tsqrmi::f32x4u*>(q + off));
+			else acc += v[k];
+		}
+	}
+	if (MODE == 1 && acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) q[0] = acc[0];
+}
+extern "C" float tsqr_selftest_stream_wg(float* q, const float* a, size_t ld, size_t m, int mode, int nwg, int reps) {
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	const int nblocks = (int)(m / 128);
+	for (int it = 0; it < reps + 1; it++) {
+		if (it == 1) (void)hipEventRecord(e0, 0);
+		if (mode == 0) hipLaunchKernelGGL((stream_wg_kernel<0>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
+		else if (mode == 1) hipLaunchKernelGGL((stream_wg_kernel<1>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
+		else hipLaunchKernelGGL((stream_wg_kernel<2>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
+	}
+	(void)hipEventRecord(e1, 0);
+	(void)hipEventSynchronize(e1);
+	float ms = 0.f;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	return ms / reps;
 }
