@@ -445,3 +445,32 @@ extern "C" float tsqr_selftest_stream_wg(float* q, const float* a, size_t ld, si
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	return ms / reps;
 }
+
+// ---- achievable v_mfma_f64_16x16x4_f64 rate: 10 independent accumulators per wave, no memory traffic ----
+__global__ __launch_bounds__(256) void mfma_f64_rate_kernel(double* out, int iters) {
+	tsqrmi::f64x4 acc[10];
+#pragma unroll
+	for (int t = 0; t < 10; t++) acc[t] = tsqrmi::f64x4{0.0, 0.0, 0.0, 0.0};
+	double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+	for (int i = 0; i < iters; i++) {
+#pragma unroll
+		for (int t = 0; t < 10; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+	}
+	double s = 0.0;
+#pragma unroll
+	for (int t = 0; t < 10; t++) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+	if (s == 123.456) out[0] = s;
+}
+extern "C" float tsqr_selftest_mfma_f64_rate(double* out, int wgs, int iters) {
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(wgs), dim3(256), 0, 0, out, iters);
+	(void)hipEventRecord(e0, 0);
+	hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(wgs), dim3(256), 0, 0, out, iters);
+	(void)hipEventRecord(e1, 0);
+	(void)hipEventSynchronize(e1);
+	float ms = 0.f;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	return ms;
+}

@@ -410,8 +410,12 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 	for (int t = 0; t < NTRI; t++) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
 	if (gw < a.nwaves) {
 		float p[NT][16];
-		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
-		for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+#ifndef TSQR_BLOCKED_CHUNKS
+		const int ch_end = a.nchunks, ch_step = a.nwaves, ch_begin = gw;
+#else
+		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw), ch_step = 1, ch_begin = gw * a.cpw;
+#endif
+		for (int ch = ch_begin; ch < ch_end; ch += ch_step) {
 			load_chunk<NT>(p, a.a, a.lda, (size_t)ch * 64, a.m, a.n, c, q);
 #pragma unroll
 			for (int rho = 0; rho < 16; rho++) {
