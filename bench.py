@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--apply-waves", type=int, default=0)
     ap.add_argument("--policy", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true", help="use the row-partitioned driver even on one GPU")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo only to rehearse the multi-rank logic with several ranks on ONE GPU")
     ap.add_argument("--ld-pad", type=int, default=0, help="leading dimension = m + pad (experiments on DRAM channel mapping)")
     args = ap.parse_args()
 
@@ -147,9 +149,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.backend == "gloo":                               # rehearsal: ranks may share a device
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     dev = torch.device("cuda", local_rank)
     m, n = args.m, args.n
     m_glob = m * world
@@ -163,6 +170,7 @@ def main():
         a_pad[:, :m] = d_a
         d_a = a_pad[:, :m]
     d_r = torch.zeros(n, n, dtype=torch.float32, device=dev)
+    eng = None
     if world == 1 and not args.force_dist:
         bf = bq.buffer(mode, bool(args.reorth), device=dev)
         bf.allocate(m, n)
@@ -243,7 +251,7 @@ def main():
                     "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
                     "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
-                    "r_factor_engine": bq.ENGINE_NAMES.get(bq.last_engine(), "?"),
+                    "r_factor_engine": bq.ENGINE_NAMES.get(eng.last_engine if eng is not None else bq.last_engine(), "?"),
                     "whole_path": {"tflops": gflops / 1e3 / world, "peak_tflops_f32_matrix": PEAK_F32_MATRIX_TFLOPS,
                                    "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
                                    "algorithmic_gbs": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e9,
