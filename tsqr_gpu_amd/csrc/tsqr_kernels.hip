@@ -465,9 +465,11 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 }
 
 // gram_bf16_kernel: the same Gram tiles on v_mfma_f32_16x16x32_bf16 with the 3-way bf16 split of both operands
-// (six exact-product terms per tile, fp32 accumulation over the wave's strip, fp64 from there on).  Memory-bound;
-// the host accepts its result only when the Cholesky pivots show nearly orthogonal columns (chol_kernel threshold).
-// Partials use the f32 MFMA C/D layout (row = 4*(lane>>4) + reg).
+// (six exact-product terms per tile).  Every K-step (32 rows) is one MFMA chain that starts from zero; its fp32 result is
+// added to fp64 totals on the vector units, so the only fp32 roundings are those inside one chain and they average out over
+// the K-steps (2^20 rows: U(0,1) input 5.5e-7 instead of 9.2e-7, U(0,1)+10 1.5e-5 instead of 2e-4; same speed, memory-bound).
+// The host accepts the result only when the Cholesky pivots show nearly orthogonal columns (chol_kernel thresholds).
+// Partials use the f32 MFMA C/D layout (row = 4*(lane>>4) + reg).  TSQR_GRAM_ACC32: the earlier fp32 totals (flush every 4 chunks).
 #ifndef TSQR_GRAM_TERMS
 #define TSQR_GRAM_TERMS 6
 #endif
@@ -482,14 +484,22 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	const int wv = threadIdx.x >> 6;
 	const int gw = blockIdx.x * 4 + wv;
 	const int c = lane & 15, q = lane >> 4;
-	// the MFMA accumulators are flushed into separate fp32 totals (round-to-nearest v_add) every TSQR_GRAM_FLUSH chunks:
 	// the MFMA's own fp32 accumulation is biased (measured: ||Q^T Q - I|| grows with the accumulation length), so the
-	// length of an MFMA accumulation chain must not depend on m
+	// length of an MFMA accumulation chain must not depend on m: one K-step per chain, fp64 from there on
+#ifndef TSQR_GRAM_ACC32
+	f32x4 acc[NTRI];
+	f64x4 tot[NTRI];
+#else
 	f32x4 acc[NTRI], tot[NTRI];
+#endif
 #pragma unroll
 	for (int t = 0; t < NTRI; t++) {
 		acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef TSQR_GRAM_ACC32
+		tot[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#else
 		tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 	}
 	if (gw < a.nwaves) {
 		float p[NT][16];
@@ -523,19 +533,29 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 				}
 				// smallest terms first inside each pass over the tiles; consecutive MFMAs hit different accumulators
 #pragma unroll
-				for (int pass = 6 - TSQR_GRAM_TERMS; pass < 6; pass++) {
+				// the nine partial products of (h+m+l)x(h+m+l), smallest first: ll ml lm mm hl lh hm mh hh; the last TSQR_GRAM_TERMS are used
+				for (int pass = 9 - TSQR_GRAM_TERMS; pass < 9; pass++) {
 					int idx = 0;
 #pragma unroll
 					for (int ti = 0; ti < NT; ti++)
 #pragma unroll
 						for (int tj = ti; tj < NT; tj++) {
-							const bf16x8 av = (pass == 0 || pass == 4) ? om[ti] : ((pass == 2) ? ol[ti] : oh[ti]);
-							const bf16x8 bv = (pass == 0 || pass == 3) ? om[tj] : ((pass == 1) ? ol[tj] : oh[tj]);
+							const bf16x8 av = (pass == 4 || pass == 6 || pass == 8) ? oh[ti] : ((pass == 1 || pass == 3 || pass == 7) ? om[ti] : ol[ti]);
+							const bf16x8 bv = (pass == 5 || pass == 7 || pass == 8) ? oh[tj] : ((pass == 2 || pass == 3 || pass == 6) ? om[tj] : ol[tj]);
 							acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[idx], 0, 0, 0);
 							idx++;
 						}
 				}
+#ifndef TSQR_GRAM_ACC32
+#pragma unroll
+				for (int t = 0; t < NTRI; t++) {
+#pragma unroll
+					for (int r = 0; r < 4; r++) tot[t][r] += (double)acc[t][r];
+					acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+				}
+#endif
 			}
+#ifdef TSQR_GRAM_ACC32
 			if (++since_flush == TSQR_GRAM_FLUSH || ch + ch_step >= ch_end) {
 				since_flush = 0;
 #pragma unroll
@@ -544,6 +564,9 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 					acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 				}
 			}
+#else
+			(void)since_flush;
+#endif
 		}
 	}
 	// workgroup sum in fp64: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the partial
