@@ -38,7 +38,13 @@ int g_apply_waves = 2048;
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 int g_apply_impl = env_int("TSQR_MI_APPLY_IMPL", 1);   // 0: per-wave chunks (apply_kernel), 1: workgroup blocks of 128 rows, 2: of 256 rows
 int g_apply_wgs = env_int("TSQR_MI_APPLY_WGS", 512);
-float g_bf16_max_scond = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);   // acceptance bound of the bf16 Gram level on S (chol_kernel)
+float g_bf16_max_scond = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);   // floor of the acceptance bound of the bf16 Gram level on S (chol_kernel)
+// Acceptance bound on the scaled conditioning S for the bf16-split Gram level.  Measured (tools/policy_accuracy.py): the level's
+// own contribution to ||Q^T Q - I||_F is about 8e-6 * S / sqrt(rows) (the fp32 roundings inside the per-K-step MFMA chains average
+// out over the K-steps), so S <= 0.12 * sqrt(rows) keeps it near 1e-6; never below the floor (short matrices), never above 128.
+float bf16_scond_limit(size_t rows) {
+	return std::min(128.0f, std::max(g_bf16_max_scond, 0.12f * sqrtf((float)rows)));
+}
 int g_debug = env_int("TSQR_MI_DEBUG", 0);
 int g_host_status = env_int("TSQR_MI_HOST_STATUS", 1);   // Cholesky status words written straight into the pinned h_wl
 int g_host_flag = env_int("TSQR_MI_HOST_FLAG", 1);       // end of call: spin on a pinned flag word instead of hipStreamSynchronize
@@ -279,14 +285,14 @@ int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float*
 }
 
 // R = chol(G) (n x n, ldr), Z = inverse(R) (NP x NP in z_buf), status word -> wq[L.status]
-int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t n, float* wq, const WqLayout& L, bool bf16, hipStream_t st,
-                unsigned* host_status = nullptr) {
+int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t rows, size_t n, float* wq, const WqLayout& L, bool bf16,
+                hipStream_t st, unsigned* host_status = nullptr) {
 	const int NT = (int)(np_of(n) / 16);
 	{
 		ProfScope ps(KC_CHOL, st);
 		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
 		                   reinterpret_cast<unsigned*>(wq + L.status), gsum, (int)n, NT, bf16 ? 1 : 0,
-		                   bf16 ? 0.03125f : 9.094947017729282e-13f, bf16 ? g_bf16_max_scond : INFINITY, host_status);
+		                   bf16 ? 0.03125f : 9.094947017729282e-13f, bf16 ? bf16_scond_limit(rows) : INFINITY, host_status);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -298,7 +304,7 @@ int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size
 	double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 16 * 256;
 	const int rc = gram_g(gsum, src, ld, m, n, wq, wr, L, bf16, st);
 	if (rc) return rc;
-	return chol_from_g(r, ldr, z_buf, gsum, n, wq, L, bf16, st, g_hsig.dev);
+	return chol_from_g(r, ldr, z_buf, gsum, m, n, wq, L, bf16, st, g_hsig.dev);
 }
 
 template <int E, int NT, bool UPD = false> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
@@ -671,7 +677,7 @@ int tsqr_mi_chol_f32(int level, float* r, size_t ldr, const double* gsum, size_t
 	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 	float* wq = reinterpret_cast<float*>(wq_v);
 	const WqLayout L = wq_layout(m, n);
-	int rc = chol_from_g(r, ldr, wq + L.z, gsum, n, wq, L, level == 2, st);
+	int rc = chol_from_g(r, ldr, wq + L.z, gsum, m, n, wq, L, level == 2, st);   // m = rows of the local block (conservative for a global G)
 	if (rc) return rc;
 	if (!status_out) return 0;                           // asynchronous: read the verdict later with tsqr_mi_chol_status
 	unsigned status = 0;
@@ -780,7 +786,7 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 				// ncclFloat64 == 8, ncclSum == 0 in nccl.h/rccl.h
 				if (allreduce(gsum, gsum, gelems, 8, 0, nccl_comm, st) != 0) { g_last_error = "ncclAllReduce failed"; return -1; }
 				float* rdst = (it == 0) ? r : rl;
-				rc = chol_from_g(rdst, (it == 0) ? ldr : n, wq + L.z, gsum, n, wq, L, level == 2, st);
+				rc = chol_from_g(rdst, (it == 0) ? ldr : n, wq + L.z, gsum, m_local * (size_t)nranks, n, wq, L, level == 2, st);
 				if (rc) return rc;
 				// q does not alias the source: apply speculatively, then look at the status (one sync per sweep, no idle gap)
 				const bool speculative = (q != src);
