@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--mode", default="fp32_tc_cor", choices=["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor"])
     ap.add_argument("--reorth", type=int, default=0)
-    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 18)   # ~10-20 s of CPU work on the GPU box host
+    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 20)   # the whole headline matrix: ~15 s of CPU work on 16 host threads
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gram-waves", type=int, default=0)
     ap.add_argument("--apply-waves", type=int, default=0)
