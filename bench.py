@@ -158,6 +158,10 @@ def main():
         else:
             dist.init_process_group("gloo")
     dev = torch.device("cuda", local_rank)
+    if world > 1:                                           # communicator set-up (lazy in RCCL) must never land in the timed region
+        warm = torch.zeros(2560, dtype=torch.float64, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
     m, n = args.m, args.n
     m_glob = m * world
     mode = bq.compute_mode[args.mode]
