@@ -614,14 +614,18 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	// speculatively and steps down when chol_kernel rejected it; with check_now panel_qr escalates per panel by itself.
 	const int first_level = !use_gram ? 0 : ((mode != TSQR_MI_FP32_NOTC || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1));
 	for (int level = first_level; level >= 0; level--) {
-		int rc = sweep(engine, level, check_now, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
-		if (rc) return rc;
-		if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, st, r, ldr, (int)n);
-		if (reorth) {
-			// second sweep on Q in place: Q <- Q * inverse(R2), R <- R2 * R   (the reference's BCGS2 plays this role)
+		int rc;
+		if (!reorth) {
+			rc = sweep(engine, level, check_now, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
+			if (rc) return rc;
+			if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, st, r, ldr, (int)n);
+		} else {
+			// two sweeps: A = Q1 R1, then Q1 = Q R2 in place, R = R2 * R1 (the reference's BCGS2 plays this role).  R1 and R2 live in
+			// the work buffer (packed, ld n); every sweep writes their upper triangles in full and rmul_kernel reads nothing else,
+			// so neither needs zero-filling, and the product is written straight into the caller's r (zeros below the diagonal)
 			float* r1 = wq + L.r1; float* r2 = wq + L.r2;
-			hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(gb), dim3(256), 0, st, r1, n, r, ldr, (int)n, (int)n);
-			HIPCHK(hipMemsetAsync(r2, 0, sizeof(float) * n * n, st));
+			rc = sweep(engine, level, check_now, q, ldq, r1, n, a, lda, m, n, wq, wr, L, h_wl, st);
+			if (rc) return rc;
 			rc = sweep(engine, level, check_now, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
 			if (rc) return rc;
 			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
@@ -638,7 +642,9 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 			}
 			if (status != 0) { g_min_level = 2; continue; }       // rejected: step down and redo
 		} else {
-			HIPCHK(hipStreamSynchronize(st));
+			rc = signal_and_wait(st);                        // completion flag in the pinned h_wl, or (rc == 1) a plain stream sync
+			if (rc < 0) return rc;
+			if (rc == 1) HIPCHK(hipStreamSynchronize(st));
 		}
 		break;
 	}
