@@ -37,7 +37,7 @@ int g_gram_waves = 2048;
 int g_apply_waves = 2048;
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 int g_apply_impl = env_int("TSQR_MI_APPLY_IMPL", 1);   // 0: per-wave chunks (apply_kernel), 1: workgroup blocks of 128 rows, 2: of 256 rows
-int g_apply_wgs = env_int("TSQR_MI_APPLY_WGS", 512);
+int g_apply_wgs = env_int("TSQR_MI_APPLY_WGS", 0);     // 0: as many workgroups as are resident at once (256 CUs x LDS-limited 2 or 3)
 float g_bf16_max_scond = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);   // floor of the acceptance bound of the bf16 Gram level on S (chol_kernel)
 // Acceptance bound on the scaled conditioning S for the bf16-split Gram level.  Measured (tools/policy_accuracy.py): the level's
 // own contribution to ||Q^T Q - I||_F is about 8e-6 * S / sqrt(rows) (the fp32 roundings inside the per-K-step MFMA chains average
@@ -323,8 +323,9 @@ template <int E, int NT, bool UPD = false> int launch_apply(const tsqrmi::ApplyA
 // workgroup-cooperative variant (apply_wg_kernel): args.nchunks = row blocks of ROWS, args.nwaves = workgroups
 template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyArgs a, hipStream_t st) {
 	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
+	constexpr int NB = (!UPD && NT == 4) ? 6 : KT * NT;  // operand blocks of Z kept in LDS (apply_wg_kernel: COMPACT)
 	const size_t lds = sizeof(float) * NP * (ROWS + 4) +
-	                   (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)(E == 2 ? 1 : 3) * KT * NT * 512 * 2);
+	                   (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)(E == 2 ? 1 : 3) * NB * 512 * 2);
 	static bool attr_done = false;
 	if (!attr_done) {
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>),
@@ -333,7 +334,16 @@ template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyAr
 	}
 	const size_t nblk = cdiv(a.m, (size_t)ROWS);
 	a.nchunks = (int)nblk;
-	a.nwaves = (int)std::min<size_t>(nblk, (size_t)g_apply_wgs);
+	// persistent grid: as many workgroups as are resident on the 256 CUs at once (LDS / register bound: 2 or 3 per CU), unless overridden
+	static int per_cu = 0;
+	if (per_cu == 0) {
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>),
+		                                                 256, lds) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 2; }
+		per_cu = std::min(nb, E == 0 ? 2 : 3);           // measured: the fp32-MFMA engine is slower with three per CU (132 vs 112 us)
+	}
+	const size_t want = g_apply_wgs > 0 ? (size_t)g_apply_wgs : (size_t)256 * per_cu;
+	a.nwaves = (int)std::min<size_t>(nblk, want);
 	a.cpw = 0;
 	hipLaunchKernelGGL((tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>), dim3(a.nwaves), dim3(256), lds, st, a);
 	return 0;
