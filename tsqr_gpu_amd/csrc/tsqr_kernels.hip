@@ -2,7 +2,7 @@
 //
 // Replaces, with a different (MI355X-first) algorithm, the device side of the reference hot path:
 //   qr32x16_batched_kernel / qr32x16_core      reference src/tcqr32x16.cu:1373-1581   -> fold_kernel
-//   tsqr_backward / tsqr_backward_layer0       reference src/tsqr.cu:143-204, 591-656  -> apply_kernel
+//   tsqr_backward / tsqr_backward_layer0       reference src/tsqr.cu:143-204, 591-656  -> apply_wg_kernel
 //   cuBLAS GEMMs between panels                reference src/blockqr.cu:92-116         -> proj_* / update_kernel
 //
 // Data layout used by every streaming kernel ("(c,q) layout"): a wave owns a chunk of 64 rows x NP
@@ -94,7 +94,7 @@ __device__ __forceinline__ void load_chunk(float (&p)[NT][16], const float* __re
 // operand taken from registers in the (c,q) layout -- the 16x16 transposes V needs are MFMAs against
 // identity slices.  The register tiles rotate after each panel so the same 16-step code serves all of
 // them (keeps the kernel inside the instruction cache).  All arithmetic is fp32; both compute modes
-// use this kernel (the mode only selects the MFMA engine of apply_kernel).
+// use this kernel (the mode only selects the MFMA engine of apply_wg_kernel).
 // ---------------------------------------------------------------------------------------------
 struct FoldArgs {
 	const float* src; size_t ld; size_t m; int n;     // source matrix (m x n, column-major)
@@ -605,143 +605,6 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	}
 }
 
-// gram_bf16_wg_kernel: the same Gram tiles, organised per WORKGROUP for the DRAM access pattern (see apply_wg_kernel):
-// a workgroup streams ROWS x NP blocks (interleaved over the grid) with loads of ROWS*4 contiguous bytes per column and
-// instruction into LDS As[col][row], the next block is prefetched into registers, and wave w takes rows
-// [w*ROWS/4, (w+1)*ROWS/4) of the block in K-steps of 32 rows: lane (c,q) reads rows 8q..8q+7 of column 16t+c (two
-// 16-byte LDS reads) -- both MFMA operands come from the same registers, so any row <-> k assignment is valid.
-// GramArgs: nchunks = number of row blocks, nwaves = number of workgroups (= gridDim.x), cpw unused.
-template <int NT, int ROWS>
-__global__ __launch_bounds__(256) void gram_bf16_wg_kernel(const GramArgs a) {
-	constexpr int NP = 16 * NT;
-	constexpr int NTRI = (NT * (NT + 1)) / 2;
-	constexpr int RS = ROWS + 4;
-	constexpr int LPC = ROWS / 4, CPI = 64 / LPC;
-	constexpr int NI = NP / (4 * CPI);
-	constexpr int KS = ROWS / 128;                       // K-steps (32 rows) per wave and block
-	constexpr int FLUSH = 2 * TSQR_GRAM_FLUSH;           // K-steps per MFMA accumulation chain (same length as gram_bf16_kernel)
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	float* As = reinterpret_cast<float*>(smem);
-	double* red = reinterpret_cast<double*>(smem);       // [2][NTRI*256], aliases As after the streaming loop
-	const int lane = threadIdx.x & 63;
-	const int wv = threadIdx.x >> 6;
-	const int c = lane & 15, q = lane >> 4;
-	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
-	f32x4 acc[NTRI], tot[NTRI];
-#pragma unroll
-	for (int t = 0; t < NTRI; t++) {
-		acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-		tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-	}
-	const int nblk = a.nchunks, nwg = a.nwaves;
-	auto load_block = [&](f32x4 (&v)[NI], int b) {
-		const size_t row = (size_t)b * ROWS + lrow;
-#pragma unroll
-		for (int k = 0; k < NI; k++) {
-			const int col = (wv + 4 * k) * CPI + lcol;
-			v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-			if (col < a.n) {
-				const float* src = a.a + (size_t)col * a.lda + row;
-				if (row + 3 < a.m) v[k] = *reinterpret_cast<const f32x4u*>(src);
-				else {
-#pragma unroll
-					for (int i = 0; i < 4; i++)
-						if (row + i < a.m) v[k][i] = src[i];
-				}
-			}
-		}
-	};
-	f32x4 v[NI];
-	int since_flush = 0;
-	int bi = blockIdx.x;
-	if (bi < nblk) load_block(v, bi);
-	for (; bi < nblk; bi += nwg) {
-#pragma unroll
-		for (int k = 0; k < NI; k++) {
-			const int col = (wv + 4 * k) * CPI + lcol;
-			*reinterpret_cast<f32x4*>(&As[col * RS + lrow]) = v[k];
-		}
-		__syncthreads();
-		if (bi + nwg < nblk) load_block(v, bi + nwg);
-#pragma unroll
-		for (int ks = 0; ks < KS; ks++) {
-			const int rb = wv * (ROWS / 4) + 32 * ks + 8 * q;
-			bf16x8 oh[NT], om[NT], ol[NT];
-#pragma unroll
-			for (int t = 0; t < NT; t++) {
-				const f32x4 x0 = *reinterpret_cast<const f32x4*>(&As[(16 * t + c) * RS + rb]);
-				const f32x4 x1 = *reinterpret_cast<const f32x4*>(&As[(16 * t + c) * RS + rb + 4]);
-				u32x4 hh, mm, ll;
-				unsigned h, m, lo;
-				split3_pair(x0[0], x0[1], h, m, lo); hh[0] = h; mm[0] = m; ll[0] = lo;
-				split3_pair(x0[2], x0[3], h, m, lo); hh[1] = h; mm[1] = m; ll[1] = lo;
-				split3_pair(x1[0], x1[1], h, m, lo); hh[2] = h; mm[2] = m; ll[2] = lo;
-				split3_pair(x1[2], x1[3], h, m, lo); hh[3] = h; mm[3] = m; ll[3] = lo;
-				oh[t] = __builtin_bit_cast(bf16x8, hh);
-				om[t] = __builtin_bit_cast(bf16x8, mm);
-				ol[t] = __builtin_bit_cast(bf16x8, ll);
-			}
-#pragma unroll
-			for (int pass = 6 - TSQR_GRAM_TERMS; pass < 6; pass++) {
-				int idx = 0;
-#pragma unroll
-				for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-					for (int tj = ti; tj < NT; tj++) {
-						const bf16x8 av = (pass == 0 || pass == 4) ? om[ti] : ((pass == 2) ? ol[ti] : oh[ti]);
-						const bf16x8 bv = (pass == 0 || pass == 3) ? om[tj] : ((pass == 1) ? ol[tj] : oh[tj]);
-						acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[idx], 0, 0, 0);
-						idx++;
-					}
-			}
-		}
-		since_flush += KS;
-		if (since_flush >= FLUSH || bi + nwg >= nblk) {
-			since_flush = 0;
-#pragma unroll
-			for (int t = 0; t < NTRI; t++) {
-				tot[t] += acc[t];
-				acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-			}
-		}
-		__syncthreads();
-	}
-	// workgroup sum in fp64 (LDS aliases As: every wave has passed the loop's last barrier)
-	double dacc[NTRI][4];
-#pragma unroll
-	for (int t = 0; t < NTRI; t++)
-#pragma unroll
-		for (int r = 0; r < 4; r++) dacc[t][r] = (double)tot[t][r];
-	if (wv >= 2) {
-#pragma unroll
-		for (int t = 0; t < NTRI; t++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) red[(size_t)(wv - 2) * NTRI * 256 + (t * 4 + r) * 64 + lane] = dacc[t][r];
-	}
-	__syncthreads();
-	if (wv < 2) {
-#pragma unroll
-		for (int t = 0; t < NTRI; t++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) dacc[t][r] += red[(size_t)wv * NTRI * 256 + (t * 4 + r) * 64 + lane];
-	}
-	__syncthreads();
-	if (wv == 1) {
-#pragma unroll
-		for (int t = 0; t < NTRI; t++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) red[(t * 4 + r) * 64 + lane] = dacc[t][r];
-	}
-	__syncthreads();
-	if (wv == 0) {
-		double* out = a.part + (size_t)blockIdx.x * NTRI * 256;
-#pragma unroll
-		for (int t = 0; t < NTRI; t++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = dacc[t][r] + red[(t * 4 + r) * 64 + lane];
-	}
-}
-
 // sub[s][e] = sum of part[b][e] over b = s, s+NSPLIT, ...   (e < nelem)
 __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ sub, const double* __restrict__ part,
                                                           int nblocks, int nelem, int nsplit) {
@@ -999,7 +862,7 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 //   cross_kernel        : S = Qb^T Ap (64 x c) on v_mfma_f32_16x16x4_f32 -- exact fp32 FMA chains in both compute modes,
 //                         both operands straight from the (c,q) registers; per-workgroup partials like the Gram engine
 //   cross_finish_kernel : summed tiles -> S into R (ldr) and -S as a 64 x 64 column-major matrix for the update
-//   apply_kernel<E,4,true> : Ap <- Ap - Qb * S   (the apply kernel with a C input and a full, non-triangular Z)
+//   apply_wg_kernel<E,4,true,ROWS> : Ap <- Ap - Qb * S   (the apply kernel with a C input and a full, non-triangular Z)
 // ---------------------------------------------------------------------------------------------
 struct CrossArgs {
 	const float* x; size_t ldx; const float* y; size_t ldy; size_t m; int ny;     // X: m x 64, Y: m x ny
@@ -1142,7 +1005,7 @@ __global__ __launch_bounds__(256) void trinv_kernel(float* __restrict__ z, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// apply_kernel: Q[rows, 0:n] = A[rows, 0:n] * Z   (Z = NP x NP upper triangular, zero padded).
+// Q[rows, 0:n] = A[rows, 0:n] * Z   (Z = NP x NP upper triangular, zero padded).
 // ENGINE 0 (fp32_notc):   v_mfma_f32_16x16x4_f32, exact fp32 FMA chains.
 // ENGINE 1 (fp32_tc_cor): v_mfma_f32_16x16x32_bf16 on a 3-way bf16 split (hi, mid, lo) of both operands;
 //   six products per tile, accumulated smallest terms first:  (mid*mid + hi*lo + lo*hi) + (hi*mid + mid*hi) + hi*hi
@@ -1155,192 +1018,8 @@ struct ApplyArgs {
 	int n_out;                          // UPD only: columns of the output / C input (n is then the contraction length, 64)
 };
 
-template <int ENGINE, int NT, bool UPD = false>
-__global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
-	// UPD = false: Q = A * Z with Z upper triangular (zero blocks skipped).  UPD = true: Q <- Q + A * Z with a full Z
-	// (the panel update Ap <- Ap - Qb * S: Z = -S, the C input is read from and written back to q).
-	constexpr int NP = 16 * NT;
-	constexpr int AS = 20;                               // column stride (floats) of the per-wave 16-row A slab
-	constexpr int ZS = NP + 16;                          // row stride of the fp32 Z image
-	constexpr int KT = (NP + 31) / 32;                   // K-steps of 32 for the bf16 engine
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	float* At_all = reinterpret_cast<float*>(smem);                       // [4][NP*AS]
-	char* zbase = smem + sizeof(float) * 4 * NP * AS;
-	const int lane = threadIdx.x & 63;
-	const int wv = threadIdx.x >> 6;
-	const int gw = blockIdx.x * 4 + wv;
-	const int c = lane & 15, q = lane >> 4;
-
-	// ---- stage Z into LDS in operand form (all 256 threads) ----
-	if constexpr (ENGINE == 0) {
-		float* Zs = reinterpret_cast<float*>(zbase);     // Zs[k][j], stride ZS
-		for (int idx = threadIdx.x; idx < NP * NP; idx += 256) {
-			const int k = idx % NP, j = idx / NP;
-			Zs[k * ZS + j] = a.z[(size_t)j * NP + k];
-		}
-	} else {
-		// Zb[part][kt][ct][lane][8] : B operand of mfma 16x16x32: lane (j=l&15, qq=l>>4) holds Z[32kt+8qq+jj][16ct+j]
-		unsigned short* Zb = reinterpret_cast<unsigned short*>(zbase);
-		for (int idx = threadIdx.x; idx < KT * NT * 64 * 8; idx += 256) {
-			const int jj = idx & 7, l = (idx >> 3) & 63, ct = (idx >> 9) % NT, kt = (idx >> 9) / NT;
-			const int k = 32 * kt + 8 * (l >> 4) + jj, j = 16 * ct + (l & 15);
-			const float v = (k < NP) ? a.z[(size_t)j * NP + k] : 0.0f;
-			unsigned h, m, lo;
-			split3(v, h, m, lo);
-			const int o = ((kt * NT + ct) * 64 + l) * 8 + jj;
-			Zb[0 * KT * NT * 512 + o] = (unsigned short)h;
-			Zb[1 * KT * NT * 512 + o] = (unsigned short)m;
-			Zb[2 * KT * NT * 512 + o] = (unsigned short)lo;
-		}
-	}
-	__syncthreads();
-	if (gw >= a.nwaves) return;
-
-	float* At = At_all + wv * NP * AS;
-#ifndef TSQR_BLOCKED_CHUNKS
-	const int ch_end = a.nchunks, ch_step = a.nwaves, ch_begin = gw;
-#else
-	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw), ch_step = 1, ch_begin = gw * a.cpw;
-#endif
-	for (int chi = ch_begin; chi < ch_end; chi += ch_step) {
-#ifndef TSQR_APPLY_FORWARD
-		const int ch = a.nchunks - 1 - chi;              // last-touched rows of A first (Infinity-Cache reuse after the R pass)
-#else
-		const int ch = chi;
-#endif
-		const size_t row0 = (size_t)ch * 64;
-		float p[NT][16];
-		load_chunk<NT>(p, a.a, a.lda, row0, a.m, a.n, c, q);
-		const bool full = (row0 + 64 <= a.m);
-#pragma unroll
-		for (int rt = 0; rt < 4; rt++) {
-			// transpose one 16-row slab through LDS: (c,q) layout -> lane <-> row
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int ct = 0; ct < NT; ct++) {
-				const f32x4 v = {p[ct][4 * rt], p[ct][4 * rt + 1], p[ct][4 * rt + 2], p[ct][4 * rt + 3]};
-				*reinterpret_cast<f32x4*>(&At[(16 * ct + c) * AS + 4 * q]) = v;
-			}
-			__builtin_amdgcn_wave_barrier();
-			f32x4 acc[NT];
-#pragma unroll
-			for (int ct = 0; ct < NT; ct++) {
-				acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-				if constexpr (UPD) {
-					const int col = 16 * ct + c;
-					if (col < a.n_out) {
-						const float* src = a.q + (size_t)col * a.ldq + row0 + 16 * rt + 4 * q;
-						if (full) acc[ct] = *reinterpret_cast<const f32x4u*>(src);
-						else {
-#pragma unroll
-							for (int i = 0; i < 4; i++) acc[ct][i] = (row0 + 16 * rt + 4 * q + i < a.m) ? src[i] : 0.0f;
-						}
-					}
-				}
-			}
-			if constexpr (ENGINE == 0) {
-				const float* Zs = reinterpret_cast<const float*>(zbase);
-#pragma unroll
-				for (int t = 0; t < NP / 4; t++) {
-					const int k = 4 * t + q;
-					const float av = At[k * AS + c];
-#pragma unroll
-					for (int ct = 0; ct < NT; ct++) {
-						if (UPD || 4 * t <= 16 * ct + 15) {   // triangular Z: Z[k][j] = 0 for k > j
-							const float bv = Zs[k * ZS + 16 * ct + c];
-							acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ct], 0, 0, 0);
-						}
-					}
-				}
-			} else {
-				const unsigned short* Zb = reinterpret_cast<const unsigned short*>(zbase);
-				constexpr int PS = KT * NT * 512;             // shorts per part
-				bf16x8 ah[KT], am[KT], al[KT];
-				{
-					float x[8 * KT];
-					unsigned hh[4 * KT], mm[4 * KT], ll[4 * KT];
-#pragma unroll
-					for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-						for (int e = 0; e < 8; e++) {
-							const int k0 = 32 * kt + 8 * q + e;
-							x[8 * kt + e] = (k0 < NP) ? At[k0 * AS + c] : 0.0f;
-						}
-					split3_pairs<4 * KT>(x, hh, mm, ll);
-#pragma unroll
-					for (int kt = 0; kt < KT; kt++) {
-						ah[kt] = __builtin_bit_cast(bf16x8, u32x4{hh[4 * kt], hh[4 * kt + 1], hh[4 * kt + 2], hh[4 * kt + 3]});
-						am[kt] = __builtin_bit_cast(bf16x8, u32x4{mm[4 * kt], mm[4 * kt + 1], mm[4 * kt + 2], mm[4 * kt + 3]});
-						al[kt] = __builtin_bit_cast(bf16x8, u32x4{ll[4 * kt], ll[4 * kt + 1], ll[4 * kt + 2], ll[4 * kt + 3]});
-					}
-				}
-				// (kt, ct) pairs with a non-zero Z block, two at a time so consecutive MFMAs hit different accumulators;
-				// inside a pair the small terms go first: (mid*mid, hi*lo, lo*hi), (hi*mid, mid*hi), hi*hi
-				auto pair = [&](auto KTc, auto CTc, auto KTd, auto CTd) {
-					constexpr int k0 = decltype(KTc)::value, c0 = decltype(CTc)::value;
-					constexpr int k1 = decltype(KTd)::value, c1 = decltype(CTd)::value;
-					const int o0 = ((k0 * NT + c0) * 64 + lane) * 8, o1 = ((k1 * NT + c1) * 64 + lane) * 8;
-					const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(&Zb[0 * PS + o0]);
-					const bf16x8 bm0 = *reinterpret_cast<const bf16x8*>(&Zb[1 * PS + o0]);
-					const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(&Zb[2 * PS + o0]);
-					const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(&Zb[0 * PS + o1]);
-					const bf16x8 bm1 = *reinterpret_cast<const bf16x8*>(&Zb[1 * PS + o1]);
-					const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(&Zb[2 * PS + o1]);
-					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k0], bm0, acc[c0], 0, 0, 0);
-					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k1], bm1, acc[c1], 0, 0, 0);
-					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bl0, acc[c0], 0, 0, 0);
-					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bl1, acc[c1], 0, 0, 0);
-					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k0], bh0, acc[c0], 0, 0, 0);
-					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[k1], bh1, acc[c1], 0, 0, 0);
-					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bm0, acc[c0], 0, 0, 0);
-					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bm1, acc[c1], 0, 0, 0);
-					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k0], bh0, acc[c0], 0, 0, 0);
-					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[k1], bh1, acc[c1], 0, 0, 0);
-					acc[c0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k0], bh0, acc[c0], 0, 0, 0);
-					acc[c1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[k1], bh1, acc[c1], 0, 0, 0);
-				};
-				using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-				using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-				if constexpr (NT == 1) {
-					pair(I0{}, I0{}, I0{}, I0{});             // one block only: second half accumulates the same products again ...
-					acc[0] = acc[0] * 0.5f;                   // ... so halve (exact); NT == 1 is not a performance case
-				} else if constexpr (NT == 2) {
-					pair(I0{}, I0{}, I0{}, I1{});
-				} else if constexpr (NT == 3) {
-					pair(I0{}, I0{}, I0{}, I1{});
-					pair(I0{}, I2{}, I1{}, I2{});             // same accumulator twice: chains serialise, still correct
-				} else {
-					pair(I0{}, I0{}, I0{}, I1{});
-					pair(I0{}, I2{}, I0{}, I3{});
-					pair(I1{}, I2{}, I1{}, I3{});
-					if constexpr (UPD) pair(I1{}, I0{}, I1{}, I1{});      // full Z: the blocks a triangular Z leaves out
-				}
-			}
-			// D layout: col = lane&15, rows 4*(lane>>4) + i of this 16-row tile
-#pragma unroll
-			for (int ct = 0; ct < NT; ct++) {
-				const int col = 16 * ct + c;
-				if (col < (UPD ? a.n_out : a.n)) {
-					float* dst = a.q + (size_t)col * a.ldq + row0 + 16 * rt + 4 * q;
-					if (full) {
-#ifndef TSQR_APPLY_CACHED_STORE
-						__builtin_nontemporal_store(acc[ct], reinterpret_cast<f32x4u*>(dst));   // streaming: do not evict A from the Infinity Cache
-#else
-						*reinterpret_cast<f32x4u*>(dst) = acc[ct];
-#endif
-					} else {
-#pragma unroll
-						for (int i = 0; i < 4; i++)
-							if (row0 + 16 * rt + 4 * q + i < a.m) dst[i] = acc[ct][i];
-					}
-				}
-			}
-		}
-	}
-}
-
 // ---------------------------------------------------------------------------------------------
-// apply_wg_kernel: the same product as apply_kernel, organised per WORKGROUP for the DRAM access pattern.
+// apply_wg_kernel: the product Q = A * Z organised per WORKGROUP for the DRAM access pattern.
 // Measured (tools/pattern_bench*.py, 2^20 x 64, lda = 2^20): a wave that touches 64 columns x 256 B per chunk copies at
 // 4.4 TB/s, a workgroup that moves ROWS*4 contiguous bytes of ONE column per instruction (loads and stores) at 5.0-5.2 TB/s,
 // independent of the power-of-two column stride.  So:
@@ -1348,7 +1027,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a) {
 //     instruction = ROWS*4 contiguous bytes per column, written to LDS as As[col][row] (row index XOR-swizzled by bit 3
 //     of the column so that the operand reads below are bank-conflict free);
 //   * the next block is prefetched into registers before the products of the current one start;
-//   * wave w multiplies rows [w*ROWS/4, (w+1)*ROWS/4): A operand = 4-byte LDS reads along k, products as in apply_kernel,
+//   * wave w multiplies rows [w*ROWS/4, (w+1)*ROWS/4): A operand = 4-byte LDS reads along k, six-product bf16 split (or exact fp32 / single fp16 product),
 //     the result tile overwrites the wave's own rows of As in place;
 //   * after a barrier the block leaves through the same linear mapping (UPD: + the C input, loaded linearly as well).
 // ENGINE 2 (fp32_tc_nocor, reference src/tcqr32x16.cu:499-560's mode): v_mfma_f32_16x16x32_f16 on fp16-rounded operands, no

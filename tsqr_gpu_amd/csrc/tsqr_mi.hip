@@ -6,7 +6,7 @@
 //   * panel width 64 instead of 16: for n <= 64 there is no inter-panel coupling at all;
 //   * R by a streaming Householder TSQR (fold_kernel) followed by a short fold tree over the per-wave
 //     R factors -- the R-stack reduction of the reference, with fan-in 4 instead of 2;
-//   * Q = A * inverse(R) on the MFMA units (apply_kernel): "indirect TSQR".  Its loss of
+//   * Q = A * inverse(R) on the MFMA units (apply_wg_kernel): "indirect TSQR".  Its loss of
 //     orthogonality grows like cond(A)*eps, slower than the reference's 16-wide block Gram-Schmidt
 //     without reorthogonalisation; Reorthogonalize=true runs a second sweep on Q (R <- R2*R), which
 //     restores ||Q^T Q - I|| to O(eps) as the reference's BCGS2 does.
@@ -36,7 +36,7 @@ constexpr int GRAM_NSPLIT = 16;
 int g_gram_waves = 2048;
 int g_apply_waves = 2048;
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-int g_apply_impl = env_int("TSQR_MI_APPLY_IMPL", 1);   // 0: per-wave chunks (apply_kernel), 1: workgroup blocks of 128 rows, 2: of 256 rows
+int g_apply_rows = env_int("TSQR_MI_APPLY_ROWS", 128);   // rows per workgroup block of apply_wg_kernel (128 or 256)
 int g_apply_wgs = env_int("TSQR_MI_APPLY_WGS", 0);     // 0: as many workgroups as are resident at once (256 CUs x LDS-limited 2 or 3)
 float g_bf16_max_scond = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);   // floor of the acceptance bound of the bf16 Gram level on S (chol_kernel)
 // Acceptance bound on the scaled conditioning S for the bf16-split Gram level.  Measured (tools/policy_accuracy.py): the level's
@@ -54,7 +54,6 @@ int g_host_flag = env_int("TSQR_MI_HOST_FLAG", 1);       // end of call: spin on
 struct HostSig { unsigned* host = nullptr; unsigned* dev = nullptr; };
 HostSig g_hsig;
 int g_reduce1 = env_int("TSQR_MI_REDUCE1", 1);         // partials -> G in one launch (gram_reduce1_kernel) instead of two
-int g_gram_impl = env_int("TSQR_MI_GRAM_IMPL", 0);     // bf16 Gram: 0 per-wave chunks, 1 workgroup blocks of 128 rows, 2 of 256 rows
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
 enum { KC_FOLD0 = 0, KC_TREE = 1, KC_TRINV = 2, KC_APPLY = 3, KC_COUPLE = 4, KC_MISC = 5, KC_GRAM = 6, KC_CHOL = 7, KC_COUNT = 8 };
@@ -225,23 +224,7 @@ int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n
 	return 0;
 }
 
-template <int NT, int ROWS> void launch_gram_wg(tsqrmi::GramArgs a, int nblocks, hipStream_t st) {
-	constexpr int NP = 16 * NT, NTRI = NT * (NT + 1) / 2;
-	const size_t lds = std::max(sizeof(float) * NP * (ROWS + 4), sizeof(double) * 2 * NTRI * 256);
-	static bool attr_done = false;
-	if (!attr_done) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_bf16_wg_kernel<NT, ROWS>),
-		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		attr_done = true;
-	}
-	const size_t nblk = cdiv(a.m, (size_t)ROWS);
-	a.nchunks = (int)nblk;
-	a.nwaves = (int)std::min<size_t>(nblk, (size_t)nblocks);   // never more workgroups than the partial buffer was sized for
-	hipLaunchKernelGGL((tsqrmi::gram_bf16_wg_kernel<NT, ROWS>), dim3(a.nwaves), dim3(256), lds, st, a);
-}
 template <int NT> int launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool bf16, hipStream_t st) {
-	if (bf16 && g_gram_impl == 1) { launch_gram_wg<NT, 128>(a, nblocks, st); return std::min<int>(nblocks, (int)cdiv(a.m, (size_t)128)); }
-	if (bf16 && g_gram_impl == 2) { launch_gram_wg<NT, 256>(a, nblocks, st); return std::min<int>(nblocks, (int)cdiv(a.m, (size_t)256)); }
 	if (bf16) hipLaunchKernelGGL(tsqrmi::gram_bf16_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
 	else hipLaunchKernelGGL(tsqrmi::gram_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
 	return nblocks;
@@ -307,20 +290,7 @@ int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size
 	return chol_from_g(r, ldr, z_buf, gsum, m, n, wq, L, bf16, st, g_hsig.dev);
 }
 
-template <int E, int NT, bool UPD = false> int launch_apply(const tsqrmi::ApplyArgs& a, hipStream_t st) {
-	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
-	const size_t lds = sizeof(float) * 4 * NP * 20 + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)3 * KT * NT * 512 * 2);
-	static bool attr_done = false;
-	if (!attr_done) {
-		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_kernel<E, NT, UPD>),
-		                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		attr_done = true;
-	}
-	const int blocks = (a.nwaves + 3) / 4;
-	hipLaunchKernelGGL((tsqrmi::apply_kernel<E, NT, UPD>), dim3(blocks), dim3(256), lds, st, a);
-	return 0;
-}
-// workgroup-cooperative variant (apply_wg_kernel): args.nchunks = row blocks of ROWS, args.nwaves = workgroups
+// apply_wg_kernel launcher: args.nchunks = row blocks of ROWS, args.nwaves = workgroups (persistent grid)
 template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyArgs a, hipStream_t st) {
 	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
 	constexpr int NB = (!UPD && NT == 4) ? 6 : KT * NT;  // operand blocks of Z kept in LDS (apply_wg_kernel: COMPACT)
@@ -349,13 +319,8 @@ template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyAr
 	return 0;
 }
 template <int E, int NT, bool UPD> int launch_apply_any(const tsqrmi::ApplyArgs& a, hipStream_t st) {
-	if constexpr (E == 2) {                              // fp32_tc_nocor exists in the workgroup kernel only
-		return launch_apply_wg<E, NT, UPD, 128>(a, st);
-	} else {
-		if (g_apply_impl == 1) return launch_apply_wg<E, NT, UPD, 128>(a, st);
-		if (g_apply_impl == 2) return launch_apply_wg<E, NT, UPD, 256>(a, st);
-		return launch_apply<E, NT, UPD>(a, st);
-	}
+	if (g_apply_rows == 256) return launch_apply_wg<E, NT, UPD, 256>(a, st);
+	return launch_apply_wg<E, NT, UPD, 128>(a, st);
 }
 template <int E> int dispatch_apply_nt(int NT, const tsqrmi::ApplyArgs& a, hipStream_t st) {
 	switch (NT) {
