@@ -128,7 +128,8 @@ int tsqr_mi_last_engine(void);
 
 /* tuning knobs (0 = keep default): waves targeted by the first fold level, chunks folded per wave on tree levels */
 void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave);
-/* waves of the Gram kernel / of the apply kernel (work-buffer sizes follow the Gram setting: set it before allocating) */
+/* waves of the Gram kernel / of the apply kernel (apply: persistent grid of apply_waves/4 workgroups; default = all that are resident
+ * at once).  Work-buffer sizes follow the Gram setting: set it before allocating. */
 void tsqr_mi_set_tuning2(int gram_waves, int apply_waves);
 
 #ifdef __cplusplus

@@ -34,7 +34,6 @@ int g_min_level = 2;     // lowest R-factor engine level the last call ended up 
 int g_gram_level = 2;    // first Gram level tried: 2 bf16-split (then fp64), 1 fp64 only
 constexpr int GRAM_NSPLIT = 16;
 int g_gram_waves = 2048;
-int g_apply_waves = 2048;
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 int g_apply_rows = env_int("TSQR_MI_APPLY_ROWS", 128);   // rows per workgroup block of apply_wg_kernel (128 or 256)
 int g_apply_wgs = env_int("TSQR_MI_APPLY_WGS", 0);     // 0: as many workgroups as are resident at once (256 CUs x LDS-limited 2 or 3)
@@ -343,11 +342,6 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
 	HIPCHK(hipGetLastError());
 	tsqrmi::ApplyArgs aa{};
 	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = z_buf;
-	const size_t nch = cdiv(m, 64);
-	const size_t target = (size_t)g_apply_waves;
-	aa.cpw = (int)std::max<size_t>(1, cdiv(nch, target));
-	aa.nchunks = (int)nch;
-	aa.nwaves = (int)cdiv(nch, (size_t)aa.cpw);
 	int rc;
 	{
 		ProfScope ps(KC_APPLY, st);
@@ -481,10 +475,6 @@ int sweep(int engine, int r_engine, bool check_now, float* q, size_t ldq, float*
 			HIPCHK(hipGetLastError());
 			tsqrmi::ApplyArgs ua{};
 			ua.a = q + B * ldq; ua.lda = ldq; ua.q = ap; ua.ldq = lda; ua.m = m; ua.n = (int)PW; ua.z = wq + L.s; ua.n_out = (int)c;
-			const size_t nch = cdiv(m, 64);
-			ua.cpw = (int)std::max<size_t>(1, cdiv(nch, (size_t)g_apply_waves));
-			ua.nchunks = (int)nch;
-			ua.nwaves = (int)cdiv(nch, (size_t)ua.cpw);
 			const int rc2 = (engine == 0) ? launch_apply_any<0, 4, true>(ua, st)
 			                              : (engine == 1 ? launch_apply_any<1, 4, true>(ua, st) : launch_apply_any<2, 4, true>(ua, st));
 			if (rc2) return rc2;
@@ -558,7 +548,7 @@ void tsqr_mi_set_tuning(int level0_waves, int tree_chunks_per_wave) {
 }
 void tsqr_mi_set_tuning2(int gram_waves, int apply_waves) {
 	if (gram_waves > 0) g_gram_waves = gram_waves;
-	if (apply_waves > 0) g_apply_waves = apply_waves;
+	if (apply_waves > 0) g_apply_wgs = std::max(1, apply_waves / 4);   // the apply kernel is launched as a persistent grid of workgroups (4 waves each)
 }
 
 int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
