@@ -123,8 +123,9 @@ def pmc_traffic(kernel_class, m, n, mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)       # reference protocol: 1 warm-up + C = 16 calls (src/test.cu:289-309)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=32)       # reference protocol: 1 warm-up + C = 16 calls (src/test.cu:289-309); a few more
+    # untimed calls let the clocks settle (0.193 vs 0.20 ms per call)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--m", type=int, default=1 << 20, help="rows per GPU")
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--mode", default="fp32_tc_cor", choices=["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor"])
