@@ -122,7 +122,8 @@ int tsqr_mi_profile_read(double* ms, long* launches, int max_classes);
  *                     else the fp64-MFMA Gram matrix, accepted down to 2^-40 (cond(A) up to ~1e6); else Householder TSQR.
  *   1 always Householder TSQR.   2 always fp64 Gram (no fallback).   3 always bf16-split Gram (no check; tests only).
  *   4 auto without the bf16-split level.
- * tsqr_mi_last_engine(): 0 Householder, 1 fp64 Gram, 2 Gram rejected -> Householder, 3 bf16-split Gram. */
+ * tsqr_mi_last_engine(): 0 Householder, 1 fp64 Gram, 2 Gram rejected -> Householder, 3 bf16-split Gram,
+ * 4 Gram rejected -> shifted Cholesky QR (shifted fp64 Cholesky + one plain fp64 sweep in place). */
 void tsqr_mi_set_policy(int policy);
 int tsqr_mi_last_engine(void);
 

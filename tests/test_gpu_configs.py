@@ -80,7 +80,7 @@ def test_c5_latms_cond_1e8_reorth(env, mode):
     d_a = harness.latms(m, n, n, s, seed=5)
     st, d_q, d_r = harness.qr(d_a, m, n, bq.compute_mode[mode], True)
     assert st == 0
-    assert bq.last_engine() in (1, 2)                                  # never the bf16-split level on such input
+    assert bq.last_engine() in (1, 2, 4)                               # never the bf16-split level on such input
     assert harness.orthogonality_fro(d_q, m, n) < 1e-5                 # O(eps) after the second sweep
     assert harness.residual(d_q, d_r, d_a, m, n) < 2e-6
     assert torch.tril(d_r.T, -1).abs().max().item() == 0.0

@@ -220,7 +220,9 @@ def test_auto_policy_escalation(bq, oracle, torch_cuda):
     sing[:, 63] = sing[:, 0] * 0.5 + sing[:, 1] * 0.25                # exact linear dependence (rank 63)
     for md in (bq.compute_mode.fp32_tc_cor, bq.compute_mode.fp32_notc):
         st, q, r = run_gpu(bq, torch_cuda, sing, md, False)
-        assert st == 0 and bq.last_engine() == 2 and oracle.residual(sing, q, r) < 2e-6
+        assert st == 0 and bq.last_engine() == 4 and oracle.residual(sing, q, r) < 2e-6      # shifted Cholesky QR
+        assert oracle.orthogonality_fro(q) < 1e-4                  # a full orthonormal basis even for the dependent column
+        assert abs(r[63, 63]) < 1e-4 * abs(r[0, 0])                # the rank deficiency shows in R
     mid = oracle.matrix_with_cond(1 << 14, 64, 1e3, seed=5)
     for reorth in (False, True):
         st, q, r = run_gpu(bq, torch_cuda, mid, bq.compute_mode.fp32_tc_cor, reorth)
@@ -230,7 +232,7 @@ def test_auto_policy_escalation(bq, oracle, torch_cuda):
     bad = oracle.matrix_with_cond(1 << 14, 64, 1e8, seed=5)
     for reorth in (False, True):
         st, q, r = run_gpu(bq, torch_cuda, bad, bq.compute_mode.fp32_tc_cor, reorth)
-        assert st == 0 and bq.last_engine() in (1, 2)              # never the bf16-split level
+        assert st == 0 and bq.last_engine() in (1, 2, 4)           # never the bf16-split level
         assert np.isfinite(q).all() and oracle.residual(bad, q, r) < 2e-6
         if reorth:
             assert oracle.orthogonality_fro(q) < 1e-5

@@ -12,11 +12,13 @@ for cond_exp in (4, 6, 8):
         bf = bq.buffer(mode, True); bf.allocate(m, n)
         call = bq.bind(q, m, r, n, a, m, m, n, bf)
         call(); torch.cuda.synchronize()
-        bq.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(8): call()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 8
+        bq.profile_enable(True)                        # per-kernel-class times in a separate pass (event bookkeeping perturbs the wall clock)
+        for _ in range(8): call()
+        torch.cuda.synchronize()
         prof = bq.profile_read(); bq.profile_enable(False)
         print('cond 1e%d %-12s %.3f ms  engine %s  orth %.2e  res %.2e  %s' % (cond_exp, mode.name, dt * 1e3, bq.ENGINE_NAMES[bq.last_engine()],
               harness.orthogonality_fro(q, m, n), harness.residual(q, r, a, m, n), {k: round(v[0] / 8, 3) for k, v in prof.items() if v[1]}), flush=True)

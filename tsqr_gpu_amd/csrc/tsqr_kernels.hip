@@ -750,7 +750,7 @@ __device__ long long g_chol_dbg[32];
 template <class LOADG>
 __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
-                                          float max_scond) {
+                                          float max_scond, double shift_coef = 0.0) {
 	__shared__ double Gs[64 * 65];               // symmetric G (assembly only): Gs[row * 65 + col]
 	__shared__ float Rf[64 * 65];                // R rows for the final store
 	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
@@ -793,6 +793,17 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 			}
 	}
 	__syncthreads();
+	if (shift_coef > 0.0) {
+		// shifted Cholesky (Fukaya et al., "Shifted Cholesky QR for computing the QR factorization of ill-conditioned matrices",
+		// SIAM J. Sci. Comput. 2020): G + s I with s = shift_coef * trace(G) >= 11 (mn + n(n+1)) u ||A||_2^2 is safely positive
+		// definite for any fp32 input; the caller runs a second (unshifted) sweep on the resulting Q
+		if (w == 0) {
+			double tr = (j < n) ? Gs[j * 65 + j] : 0.0;
+			for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+			if (j < n) Gs[j * 65 + j] += shift_coef * tr;
+		}
+		__syncthreads();
+	}
 	double g[16], mm[16];
 #pragma unroll
 	for (int s = 0; s < 16; s++) {
@@ -852,8 +863,8 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 
 __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                                    const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio,
-                                                   float max_scond, unsigned* __restrict__ host_status) {
-	chol_body(r, ldr, z, status, host_status, [&](int e) { return gsum[e]; }, n, NT, f32_layout, min_ratio, max_scond);
+                                                   float max_scond, unsigned* __restrict__ host_status, double shift_coef) {
+	chol_body(r, ldr, z, status, host_status, [&](int e) { return gsum[e]; }, n, NT, f32_layout, min_ratio, max_scond, shift_coef);
 }
 
 // ---------------------------------------------------------------------------------------------

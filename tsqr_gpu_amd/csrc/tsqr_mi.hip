@@ -52,6 +52,8 @@ int g_host_flag = env_int("TSQR_MI_HOST_FLAG", 1);       // end of call: spin on
 // dev = device-visible alias of h_wl (null when it is not pinned host memory: then a 4-byte copy is enqueued as before).
 struct HostSig { unsigned* host = nullptr; unsigned* dev = nullptr; };
 HostSig g_hsig;
+int g_shifted = env_int("TSQR_MI_SHIFTED", 1);         // shifted Cholesky QR (two-step) before the Householder fallback
+bool g_used_shift = false, g_used_householder = false;
 int g_reduce1 = env_int("TSQR_MI_REDUCE1", 1);         // partials -> G in one launch (gram_reduce1_kernel) instead of two
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
@@ -160,7 +162,7 @@ GramPlan gram_plan(size_t m, size_t n) {
 }
 
 // layout of wq (floats): [stack_b][Z: 4096][S: 4096][part: NSLAB*4096][R1 copy: n*n][R2: n*n][gram sub-sums][status]
-struct WqLayout { size_t z, s, part, r1, r2, gsub, status, total; };
+struct WqLayout { size_t z, s, part, r1, r2, r3, r4, gsub, status, total; };
 WqLayout wq_layout(size_t m, size_t n) {
 	const Plan p = make_plan(m, n);
 	WqLayout L{};
@@ -171,6 +173,8 @@ WqLayout wq_layout(size_t m, size_t n) {
 	L.part = o;                                          // (unused since the MFMA coupling kernels)
 	L.r1 = o; o += n * n;
 	L.r2 = o; o += n * n;
+	L.r3 = o; o += 4096;                                 // panel-local R1, R2 of the shifted-Cholesky two-step (<= 64 x 64 each)
+	L.r4 = o; o += 4096;
 	o = (o + 63) & ~(size_t)63;
 	L.gsub = o; o += (size_t)(GRAM_NSPLIT + 1) * 16 * 256 * 2;    // sub-sums + summed tiles (Gram: 10 tiles, coupling: 16)
 	L.status = o; o += 64;
@@ -268,13 +272,14 @@ int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float*
 
 // R = chol(G) (n x n, ldr), Z = inverse(R) (NP x NP in z_buf), status word -> wq[L.status]
 int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t rows, size_t n, float* wq, const WqLayout& L, bool bf16,
-                hipStream_t st, unsigned* host_status = nullptr) {
+                hipStream_t st, unsigned* host_status = nullptr, double shift_coef = 0.0) {
 	const int NT = (int)(np_of(n) / 16);
 	{
 		ProfScope ps(KC_CHOL, st);
 		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
 		                   reinterpret_cast<unsigned*>(wq + L.status), gsum, (int)n, NT, bf16 ? 1 : 0,
-		                   bf16 ? 0.03125f : 9.094947017729282e-13f, bf16 ? bf16_scond_limit(rows) : INFINITY, host_status);
+		                   shift_coef > 0.0 ? 0.0f : (bf16 ? 0.03125f : 9.094947017729282e-13f),
+		                   bf16 ? bf16_scond_limit(rows) : INFINITY, host_status, shift_coef);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -442,7 +447,44 @@ int panel_qr(int engine, int r_engine, bool check_now, float* qp, size_t ldq, fl
 			return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st, /*z_ready=*/true);
 		}
 	}
+	if (r_engine >= 1 && check_now && g_shifted && g_policy == 0) {
+		// Both Gram levels rejected the panel (cond beyond ~1e6, or rank deficient).  Shifted Cholesky QR: the fp64 Gram matrix is
+		// still in the work buffer; R1 = chol(G + s I) always exists, Q1 = A inverse(R1) has cond(Q1) <~ 1e5, and one unshifted fp64
+		// sweep on Q1 in place finishes the panel: A = Q (R2 R1).  About 2x faster than the Householder fold below and, after that
+		// second step, at least as orthogonal as its single indirect sweep.
+		double* gsum = reinterpret_cast<double*>(wq + L.gsub) + (size_t)GRAM_NSPLIT * 16 * 256;
+		float* r1 = wq + L.r3; float* r2 = wq + L.r4;
+		const double coef = 11.0 * ((double)m * (double)c + (double)c * (double)(c + 1)) * 1.1102230246251565e-16;
+		rc = chol_from_g(r1, c, wq + L.z, gsum, m, c, wq, L, /*bf16=*/false, st, g_hsig.dev, coef);
+		if (rc) return rc;
+		unsigned status = 0;
+		rc = read_status(wq, L, h_pinned, st, &status);
+		if (rc) return rc;
+		if (status == 0) {
+			rc = apply_rinv(engine, qp, ldq, ap, lda, r1, c, m, c, wq + L.z, st, /*z_ready=*/true);
+			if (rc) return rc;
+			rc = gram_r(r2, c, wq + L.z, qp, ldq, m, c, wq, wr, L, /*bf16=*/false, st);
+			if (rc) return rc;
+			rc = read_status(wq, L, h_pinned, st, &status);
+			if (rc) return rc;
+			if (status == 0) {
+				rc = apply_rinv(engine, qp, ldq, qp, ldq, r2, c, m, c, wq + L.z, st, /*z_ready=*/true);
+			} else {                                         // (not observed) finish with the Householder engine on Q1: A = Q (R2' R1) all the same
+				rc = fold_r(r2, c, qp, ldq, m, c, wq, wr, st);
+				if (rc) return rc;
+				rc = apply_rinv(engine, qp, ldq, qp, ldq, r2, c, m, c, wq + L.z, st);
+			}
+			if (rc) return rc;
+			const unsigned gbp = (unsigned)std::min<size_t>(1024, cdiv(c * c, 256));
+			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gbp), dim3(256), 0, st, rpp, ldr, r2, c, r1, c, (int)c);
+			HIPCHK(hipGetLastError());
+			g_min_level = 0;
+			g_used_shift = true;
+			return 0;
+		}
+	}
 	g_min_level = 0;
+	g_used_householder = true;
 	rc = fold_r(rpp, ldr, ap, lda, m, c, wq, wr, st);
 	if (rc) return rc;
 	return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st);
@@ -573,6 +615,7 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
 	g_last_engine = 0;
 	g_min_level = 2;
+	g_used_shift = g_used_householder = false;
 	resolve_host_sig(h_wl);
 
 	// R-factor engine levels: 2 bf16-split Gram (memory-bound), 1 fp64 Gram, 0 Householder TSQR.  Deferred mode runs a level
@@ -581,7 +624,10 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	for (int level = first_level; level >= 0; level--) {
 		int rc;
 		if (!reorth) {
-			rc = sweep(engine, level, check_now, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
+			// level 0 reached in the speculative (deferred) mode: both Gram levels were rejected.  Re-enter at the fp64 level with
+			// immediate checks so that panel_qr can take the shifted-Cholesky path before the Householder fold
+			const bool retry_checked = (level == 0 && deferred && g_shifted);
+			rc = sweep(engine, retry_checked ? 1 : level, check_now || retry_checked, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
 			if (rc) return rc;
 			if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, st, r, ldr, (int)n);
 		} else {
@@ -613,7 +659,7 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 		}
 		break;
 	}
-	g_last_engine = !use_gram ? 0 : (g_min_level == 2 ? 3 : (g_min_level == 1 ? 1 : 2));
+	g_last_engine = !use_gram ? 0 : (g_used_householder ? 2 : (g_used_shift ? 4 : (g_min_level == 2 ? 3 : (g_min_level == 1 ? 1 : 2))));
 	prof_collect();
 	return TSQR_MI_SUCCESS;
 }
