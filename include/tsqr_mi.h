@@ -87,7 +87,9 @@ int tsqr_mi_apply_rinv_f32(int mode, float* q, size_t ldq, const float* a, size_
 size_t tsqr_mi_gram_elems(size_t n);
 int tsqr_mi_gram_f32(int level, double* gsum, const float* a, size_t lda, size_t m, size_t n, void* wq, void* wr, void* stream);
 int tsqr_mi_chol_f32(int level, float* r, size_t ldr, const double* gsum, size_t m, size_t n, void* wq, unsigned* status_out, void* stream);
-/* status_out == NULL above: asynchronous (no stream sync); the verdict is then read with tsqr_mi_chol_status (blocking) -- lets a
+/* level 3 = shifted Cholesky (G + s I, s = 11 (m n + n (n+1)) 2^-53 trace(G)) of an fp64 Gram matrix: always accepted for finite
+ * input; the caller must follow with one more plain sweep on the resulting Q and multiply the R factors (tsqr_mi_rmul_f32).
+ * status_out == NULL above: asynchronous (no stream sync); the verdict is then read with tsqr_mi_chol_status (blocking) -- lets a
  * caller enqueue tsqr_mi_apply_z_f32 speculatively behind the Cholesky and pay one synchronisation per sweep. */
 int tsqr_mi_chol_status(const void* wq, size_t m, size_t n, unsigned* status_out, void* stream);
 int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t lda, size_t m, size_t n, void* wq, void* stream);

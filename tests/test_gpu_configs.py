@@ -132,3 +132,21 @@ def test_cpp_dist_entry_point_over_rccl_single_rank(env, mode, policy, want, reo
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+def test_row_partitioned_driver_ill_conditioned_shifted_path(env, mode):
+    """cond 1e8 through the row-partitioned driver (one rank): both Gram levels reject, the shifted-Cholesky step + one plain
+    fp64 sweep finish the first sweep (engine 4), the reorthogonalisation sweep brings ||Q^T Q - I||_F to O(eps)."""
+    torch, bq, harness, oracle = env
+    from tsqr_gpu_amd import dist as tdist
+    m, n = 1 << 17, 64
+    s = torch.logspace(0, -8, n, dtype=torch.float64)
+    d_a = harness.latms(m, n, n, s, seed=9)
+    d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+    eng = tdist.HipEngine(bq.compute_mode[mode], m, n, 1)
+    assert tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=True) == 0
+    torch.cuda.synchronize()
+    assert eng.last_engine == 4
+    assert harness.orthogonality_fro(d_q, m, n) < 1e-5 and harness.residual(d_q, d_r, d_a, m, n) < 2e-6
+    assert torch.tril(d_r.T, -1).abs().max().item() == 0.0

@@ -690,11 +690,14 @@ int tsqr_mi_gram_f32(int level, double* gsum, const float* a, size_t lda, size_t
 }
 
 int tsqr_mi_chol_f32(int level, float* r, size_t ldr, const double* gsum, size_t m, size_t n, void* wq_v, unsigned* status_out, void* stream) {
-	if (m == 0 || n == 0 || n > PW || (level != 1 && level != 2)) return TSQR_MI_ERROR_INVALID_SIZE;
+	// level 3: shifted Cholesky of an fp64 (level-1) Gram matrix, G + s I with s from the row count m passed here (the caller
+	// passes the GLOBAL row count for a row-partitioned matrix); the caller then runs one more plain sweep on the resulting Q
+	if (m == 0 || n == 0 || n > PW || (level != 1 && level != 2 && level != 3)) return TSQR_MI_ERROR_INVALID_SIZE;
 	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 	float* wq = reinterpret_cast<float*>(wq_v);
 	const WqLayout L = wq_layout(m, n);
-	int rc = chol_from_g(r, ldr, wq + L.z, gsum, m, n, wq, L, level == 2, st);   // m = rows of the local block (conservative for a global G)
+	const double coef = (level == 3) ? 11.0 * ((double)m * (double)n + (double)n * (double)(n + 1)) * 1.1102230246251565e-16 : 0.0;
+	int rc = chol_from_g(r, ldr, wq + L.z, gsum, m, n, wq, L, level == 2, st, nullptr, coef);   // m = rows (local is conservative for levels 1, 2)
 	if (rc) return rc;
 	if (!status_out) return 0;                           // asynchronous: read the verdict later with tsqr_mi_chol_status
 	unsigned status = 0;

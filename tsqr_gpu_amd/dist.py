@@ -96,6 +96,16 @@ class HipEngine:
             raise RuntimeError("tsqr_mi_chol_status -> %d %s" % (st, bq.last_error()))
         return int(status.value)
 
+    def chol_shifted(self, g, m, r):
+        """r <- chol(G + s I) of the fp64 Gram tiles in g (level 3 of tsqr_mi_chol_f32); inverse(R) stays in the work buffer."""
+        import ctypes
+        status = ctypes.c_uint(0)
+        st = bq.lib().tsqr_mi_chol_f32(3, r.data_ptr(), self.n, g.data_ptr(), m, self.n, self.wq.data_ptr(),
+                                       ctypes.byref(status), self._stream())
+        if st != 0:
+            raise RuntimeError("tsqr_mi_chol_f32(shifted) -> %d %s" % (st, bq.last_error()))
+        return int(status.value)
+
     def apply_z(self, q, ldq, a, lda, m):
         st = bq.lib().tsqr_mi_apply_z_f32(int(self.mode), q.data_ptr(), ldq, a.data_ptr(), lda, m, self.n,
                                           self.wq.data_ptr(), self._stream())
@@ -117,6 +127,7 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
     src, ld_src = a, lda
     for sweep in range(2 if reorthogonalize else 1):
         r_new = None
+        r_shift = None
         if getattr(engine, "use_gram", False):
             for level in getattr(engine, "gram_levels", (2, 1)):   # bf16-split Gram, then fp64 Gram; every rank takes the same decision
                 g = engine.gram(level, src, ld_src, m_local)
@@ -138,9 +149,27 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
                     r_new = r_try
                     engine.last_engine = max(getattr(engine, "last_engine", 0), 3 if level == 2 else 1)
                     break
+            if r_new is None and hasattr(engine, "chol_shifted"):
+                # both Gram levels rejected (cond beyond ~1e6 or rank deficient): shifted Cholesky of the fp64 Gram matrix that is
+                # still in g (already all-reduced), Q1 = src * inverse(R1); the rest of the sweep factors Q1 in place (one plain
+                # fp64 Gram level, else the Householder engine) and R = R_second * R1
+                r_shift = engine.empty(n, n)
+                if engine.chol_shifted(g, m_local, r_shift) == 0:
+                    engine.apply_z(q, ldq, src, ld_src, m_local)
+                    src, ld_src = q, ldq
+                    g = engine.gram(1, q, ldq, m_local)
+                    if world > 1:
+                        dist.all_reduce(g, group=group)
+                    r2 = engine.empty(n, n)
+                    if engine.chol(1, g, m_local, r2) == 0:
+                        engine.apply_z(q, ldq, q, ldq, m_local)
+                        r_new = r2
+                        engine.last_engine = 4
+                else:
+                    r_shift = None
             if r_new is None:
                 engine.last_engine = 2
-        if r_new is None:                              # Householder TSQR engine
+        if r_new is None:                              # Householder TSQR engine (on Q1 after a shifted step)
             r_loc = engine.empty(n, n)
             engine.local_r(src, ld_src, m_local, r_loc)
             if world > 1:
@@ -153,6 +182,9 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
             else:
                 r_new = r_loc
             engine.apply_rinv(q, ldq, src, ld_src, m_local, r_new)
+        if r_shift is not None:
+            engine.rmul(r_shift, r_new)                # R of this sweep = R_second * R1
+            r_new = r_shift
         if sweep == 0:
             if r_new is not r:
                 r.copy_(r_new)
