@@ -208,13 +208,19 @@ def test_all_r_engines(bq, oracle, torch_cuda, policy, mode, m, n):
 
 
 def test_auto_policy_escalation(bq, oracle, torch_cuda):
-    """auto: fp32_notc -> fp64 Gram (never the bf16-split level); fp32_tc_cor -> bf16-split Gram for nearly orthogonal columns,
-    fp64 Gram for moderate cond; both -> Householder when the Cholesky factorisation is rejected (rank deficient, cond ~1e8)."""
+    """auto: bf16-split Gram for nearly orthogonal columns (any mode), fp64 Gram for moderate cond, shifted Cholesky QR when
+    the plain Cholesky factorisation is rejected (rank deficient, cond ~1e8); policy 4 skips the bf16-split level."""
     a = oracle.uniform_matrix(4096, 64, seed=3)
     run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_tc_cor, False)
     assert bq.last_engine() == 3
     run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_notc, False)
-    assert bq.last_engine() == 1
+    assert bq.last_engine() == 3                                   # same R-factor levels for every mode
+    bq.set_policy(bq.POLICY_AUTO_NO_BF16) if hasattr(bq, "POLICY_AUTO_NO_BF16") else bq.set_policy(4)
+    try:
+        run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_notc, False)
+        assert bq.last_engine() == 1                               # policy 4: auto without the bf16-split level
+    finally:
+        bq.set_policy(bq.POLICY_AUTO)
     # a matrix whose Gram matrix is numerically singular in fp64 must end in the Householder engine
     sing = oracle.uniform_matrix(8192, 64, seed=8)
     sing[:, 63] = sing[:, 0] * 0.5 + sing[:, 1] * 0.25                # exact linear dependence (rank 63)
@@ -238,7 +244,7 @@ def test_auto_policy_escalation(bq, oracle, torch_cuda):
             assert oracle.orthogonality_fro(q) < 1e-5
 
 
-@pytest.mark.parametrize("mode,use_gram,want_engine", [("fp32_notc", None, 1), ("fp32_tc_cor", None, 3),
+@pytest.mark.parametrize("mode,use_gram,want_engine", [("fp32_notc", None, 3), ("fp32_tc_cor", None, 3),
                                                        ("fp32_notc", False, 0), ("fp32_tc_cor", False, 0)])
 @pytest.mark.parametrize("reorth", [False, True])
 def test_dist_driver_single_rank(bq, oracle, torch_cuda, mode, use_gram, want_engine, reorth):

@@ -604,8 +604,9 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	float* wq = reinterpret_cast<float*>(wq_v);
 	float* wr = reinterpret_cast<float*>(wr_v);
 	const WqLayout L = wq_layout(m, n);
-	// auto policy: fp32_tc_cor starts at the bf16-split Gram level, fp32_notc at the fp64 Gram level (faster AND more
-	// orthogonal than the fp32 Householder fold: 3.5e-7 vs 2.1e-6 at 2^20 x 64); both fall back to Householder TSQR
+	// auto policy: every mode starts at the bf16-split Gram level (exact products, fp64 accumulation across K-steps: more accurate
+	// than any plain fp32 evaluation of A^T A, accepted only for well-conditioned panels), then the fp64 Gram level, the shifted
+	// Cholesky QR step and the Householder fold; the mode selects the MFMA engine of the apply pass.  Policy 4 skips the bf16 level.
 	const bool use_gram = (g_policy == 2) || (g_policy == 0);
 	const bool may_fall_back = use_gram && g_policy == 0;
 	// single panel, single sweep: run speculatively and look at the status at the final sync (A is untouched for n <= 64);
@@ -620,7 +621,7 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 
 	// R-factor engine levels: 2 bf16-split Gram (memory-bound), 1 fp64 Gram, 0 Householder TSQR.  Deferred mode runs a level
 	// speculatively and steps down when chol_kernel rejected it; with check_now panel_qr escalates per panel by itself.
-	const int first_level = !use_gram ? 0 : ((mode != TSQR_MI_FP32_NOTC || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1));
+	const int first_level = !use_gram ? 0 : g_gram_level;
 	for (int level = first_level; level >= 0; level--) {
 		int rc;
 		if (!reorth) {
@@ -791,7 +792,7 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 	float* rl = wq + L.r2;                               // local R, n x n packed (ld n)
 	const float* src = a; size_t ld_src = lda;
 	const bool use_gram = (g_policy == 2) || (g_policy == 0);
-	const int first_level = (mode != TSQR_MI_FP32_NOTC || g_policy == 2) ? g_gram_level : std::min(g_gram_level, 1);
+	const int first_level = g_gram_level;
 	nccl_allreduce_t allreduce = use_gram ? resolve_allreduce() : nullptr;
 	for (int it = 0; it < (reorth ? 2 : 1); it++) {
 		int rc;

@@ -32,10 +32,9 @@ class HipEngine:
         self.mode = bq.compute_mode(mode)
         self.n = n
         self.m_local = m_local
-        # same default policy as tsqr_mi_qr_f32: Gram engine (fp32_tc_cor: bf16-split level, then fp64; fp32_notc: fp64 level),
-        # Householder TSQR as the fallback
+        # same default policy as tsqr_mi_qr_f32: bf16-split Gram level, then fp64 Gram, shifted Cholesky QR, Householder TSQR
         self.use_gram = True if use_gram is None else bool(use_gram)
-        self.gram_levels = (2, 1) if self.mode == bq.compute_mode.fp32_tc_cor else (1,)
+        self.gram_levels = (2, 1)
         self.last_engine = 0
         rows = max(m_local, world_size * n)
         self.wq = torch.empty(max(bq.get_working_q_size(rows, n), 1), dtype=torch.float32, device="cuda")
