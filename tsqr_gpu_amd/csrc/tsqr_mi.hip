@@ -427,11 +427,16 @@ int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStrea
 	return 0;
 }
 
+constexpr int R_SHIFT_DIRECT = 9;
 // R factor (and Q) of one <= 64-column panel.  use_gram: Gram/Cholesky engine, otherwise the Householder TSQR engine.
 // check_now: verify the Gram engine's status immediately (one stream sync) and fall back to Householder on breakdown.
 int panel_qr(int engine, int r_engine, bool check_now, float* qp, size_t ldq, float* rpp, size_t ldr, const float* ap, size_t lda,
              size_t m, size_t c, float* wq, float* wr, const WqLayout& L, unsigned* h_pinned, hipStream_t st) {
 	int rc;
+	// R_SHIFT_DIRECT: the caller has just seen the fp64 Gram level reject this very panel (speculative single-panel mode); its
+	// Gram matrix is still in the work buffer, so go straight to the shifted-Cholesky step
+	const bool direct_shift = (r_engine == R_SHIFT_DIRECT);
+	if (direct_shift) r_engine = 0;
 	for (int e = r_engine; e >= 1; e--) {                // 2: bf16-split Gram, 1: fp64 Gram; with check_now a rejected level escalates
 		rc = gram_r(rpp, ldr, wq + L.z, ap, lda, m, c, wq, wr, L, e == 2, st);
 		if (rc) return rc;
@@ -447,7 +452,7 @@ int panel_qr(int engine, int r_engine, bool check_now, float* qp, size_t ldq, fl
 			return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st, /*z_ready=*/true);
 		}
 	}
-	if (r_engine >= 1 && check_now && g_shifted && g_policy == 0) {
+	if ((direct_shift || (r_engine >= 1 && check_now)) && g_shifted && g_policy == 0) {
 		// Both Gram levels rejected the panel (cond beyond ~1e6, or rank deficient).  Shifted Cholesky QR: the fp64 Gram matrix is
 		// still in the work buffer; R1 = chol(G + s I) always exists, Q1 = A inverse(R1) has cond(Q1) <~ 1e5, and one unshifted fp64
 		// sweep on Q1 in place finishes the panel: A = Q (R2 R1).  About 2x faster than the Householder fold below and, after that
@@ -625,10 +630,10 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	for (int level = first_level; level >= 0; level--) {
 		int rc;
 		if (!reorth) {
-			// level 0 reached in the speculative (deferred) mode: both Gram levels were rejected.  Re-enter at the fp64 level with
-			// immediate checks so that panel_qr can take the shifted-Cholesky path before the Householder fold
-			const bool retry_checked = (level == 0 && deferred && g_shifted);
-			rc = sweep(engine, retry_checked ? 1 : level, check_now || retry_checked, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
+			// level 0 reached in the speculative (deferred) mode: both Gram levels were rejected and the fp64 Gram matrix of A is
+			// still in the work buffer: panel_qr takes the shifted-Cholesky path on it before the Householder fold
+			const bool retry_checked = (level == 0 && deferred && g_shifted && first_level >= 1);
+			rc = sweep(engine, retry_checked ? R_SHIFT_DIRECT : level, check_now || retry_checked, q, ldq, r, ldr, a, lda, m, n, wq, wr, L, h_wl, st);
 			if (rc) return rc;
 			if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, st, r, ldr, (int)n);
 		} else {
