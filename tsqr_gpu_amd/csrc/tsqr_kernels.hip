@@ -1027,6 +1027,8 @@ struct ApplyArgs {
 	const float* z;                     // NP x NP, ld NP
 	int nchunks; int cpw; int nwaves;
 	int n_out;                          // UPD only: columns of the output / C input (n is then the contraction length, 64)
+	const unsigned* skip_status;        // optional: the kernel returns at once when *skip_status != 0 (the Cholesky kernel
+	                                    // rejected its Gram matrix: a speculatively enqueued apply then costs a launch, not a pass)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1062,6 +1064,7 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* As = reinterpret_cast<float*>(smem);
 	char* zbase = smem + sizeof(float) * NP * RS;
+	if (a.skip_status && a.skip_status[0] != 0) return;  // uniform over the grid
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	const int c = lane & 15, q = lane >> 4;

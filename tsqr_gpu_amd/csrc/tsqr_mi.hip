@@ -337,7 +337,7 @@ template <int E> int dispatch_apply_nt(int NT, const tsqrmi::ApplyArgs& a, hipSt
 
 // q = a * inverse(r); n <= 64; z_buf: 4096 floats of scratch
 int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, const float* r, size_t ldr,
-               size_t m, size_t n, float* z_buf, hipStream_t st, bool z_ready = false) {
+               size_t m, size_t n, float* z_buf, hipStream_t st, bool z_ready = false, const unsigned* skip_status = nullptr) {
 	const size_t NP = np_of(n);
 	const int NT = (int)(NP / 16);
 	if (!z_ready) {
@@ -346,7 +346,7 @@ int apply_rinv(int engine, float* q, size_t ldq, const float* a, size_t lda, con
 	}
 	HIPCHK(hipGetLastError());
 	tsqrmi::ApplyArgs aa{};
-	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = z_buf;
+	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = z_buf; aa.skip_status = skip_status;
 	int rc;
 	{
 		ProfScope ps(KC_APPLY, st);
@@ -449,7 +449,9 @@ int panel_qr(int engine, int r_engine, bool check_now, float* qp, size_t ldq, fl
 		}
 		if (ok) {
 			g_min_level = std::min(g_min_level, e);
-			return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st, /*z_ready=*/true);
+			// speculative (unchecked) launch under the auto policy: the kernel itself skips the pass when the level was rejected
+			const unsigned* skip = (!check_now && g_policy == 0) ? reinterpret_cast<const unsigned*>(wq + L.status) : nullptr;
+			return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st, /*z_ready=*/true, skip);
 		}
 	}
 	if ((direct_shift || (r_engine >= 1 && check_now)) && g_shifted && g_policy == 0) {
@@ -725,7 +727,9 @@ int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t l
 	if (engine < 0) return TSQR_MI_ERROR_UNSUPPORTED;
 	float* wq = reinterpret_cast<float*>(wq_v);
 	const WqLayout L = wq_layout(m, n);
-	return apply_rinv(engine, q, ldq, a, lda, nullptr, 0, m, n, wq + L.z, reinterpret_cast<hipStream_t>(stream), /*z_ready=*/true);
+	// under the auto policy a rejected Cholesky (status word != 0) turns a speculatively enqueued apply into a no-op
+	const unsigned* skip = (g_policy == 0) ? reinterpret_cast<const unsigned*>(wq + L.status) : nullptr;
+	return apply_rinv(engine, q, ldq, a, lda, nullptr, 0, m, n, wq + L.z, reinterpret_cast<hipStream_t>(stream), /*z_ready=*/true, skip);
 }
 
 // ---- harness support: the reference's accuracy metrics evaluated on the device in fp64 (src/validation.cu, src/test.cu:147-165) ----
@@ -817,7 +821,8 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, si
 				// q does not alias the source: apply speculatively, then look at the status (one sync per sweep, no idle gap)
 				const bool speculative = (q != src);
 				if (speculative) {
-					rc = apply_rinv(engine, q, ldq, src, ld_src, nullptr, 0, m_local, n, wq + L.z, st, /*z_ready=*/true);
+					const unsigned* skip = (g_policy == 0) ? reinterpret_cast<const unsigned*>(wq + L.status) : nullptr;
+					rc = apply_rinv(engine, q, ldq, src, ld_src, nullptr, 0, m_local, n, wq + L.z, st, /*z_ready=*/true, skip);
 					if (rc) return rc;
 				}
 				unsigned status = 0;
