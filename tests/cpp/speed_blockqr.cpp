@@ -1,0 +1,45 @@
+// The reference's speed protocol (src/test.cu:257-343: one warm-up call, then wall clock over C = 16 blocking calls) from a C++
+// caller of include/tsqr/blockqr.hpp -- no Python, no torch: what a user of the reference sees after switching.
+// Prints the reference's speed CSV line plus the algorithmic TFLOP/s (F_QR = 4MN^2 - 4/3 N^3).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <tsqr/blockqr.hpp>
+
+template <mtk::qr::compute_mode mode, bool reorth>
+int speed(const std::size_t M, const std::size_t N, const unsigned C, const char* mode_name) {
+	std::vector<float> h_a(M * N);
+	unsigned long long s = 88172645463325252ull;                     // xorshift64: U(-1,1)
+	for (auto& v : h_a) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (float)((double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0); }
+	float *d_a, *d_q, *d_r;
+	if (hipMalloc((void**)&d_a, sizeof(float) * M * N) != hipSuccess || hipMalloc((void**)&d_q, sizeof(float) * M * N) != hipSuccess ||
+	    hipMalloc((void**)&d_r, sizeof(float) * N * N) != hipSuccess) return 1;
+	(void)hipMemcpy(d_a, h_a.data(), sizeof(float) * M * N, hipMemcpyHostToDevice);
+	(void)hipMemset(d_r, 0, sizeof(float) * N * N);
+	mtk::qr::buffer<mode, reorth> buffer;
+	buffer.allocate(M, N);
+	hipStream_t stream;
+	(void)hipStreamCreate(&stream);
+	if (mtk::qr::qr<mode, reorth>(d_q, M, d_r, N, d_a, M, M, N, buffer, stream) != mtk::qr::success_factorization) return 1;
+	const auto t0 = std::chrono::system_clock::now();
+	for (unsigned c = 0; c < C; c++) mtk::qr::qr<mode, reorth>(d_q, M, d_r, N, d_a, M, M, N, buffer, stream);
+	const auto t1 = std::chrono::system_clock::now();
+	const double el = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-9 / C;
+	const double fqr = 4.0 * M * N * N - 4.0 / 3.0 * N * N * N;
+	std::printf("%zu,%zu,1,float,%s,%d,%e,%e,%zu\n", M, N, mode_name, (int)reorth, el, fqr / el / 1e12, buffer.get_device_memory_size());
+	(void)hipFree(d_a); (void)hipFree(d_q); (void)hipFree(d_r); (void)hipStreamDestroy(stream);
+	return 0;
+}
+
+int main(int argc, char** argv) {
+	const std::size_t M = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : (1u << 20);
+	const std::size_t N = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 64;
+	const unsigned C = argc > 3 ? (unsigned)std::atoi(argv[3]) : 16;
+	std::printf("m,n,rand_range,type,compute_mode,reorthogonalization,elapsed_time,tflops_fqr,working_memory_size\n");
+	int rc = 0;
+	rc |= speed<mtk::qr::fp32_tc_cor, false>(M, N, C, "fp32_tc_cor");
+	rc |= speed<mtk::qr::fp32_notc, false>(M, N, C, "fp32_notc");
+	rc |= speed<mtk::qr::fp32_tc_cor, true>(M, N, C, "fp32_tc_cor");
+	return rc;
+}

@@ -183,6 +183,14 @@ def test_cpp_sample_through_header(bq, torch_cuda):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0 and "SAMPLE OK" in out.stdout, out.stdout + out.stderr
+    # the reference's speed protocol from C++ (no Python in the loop): schema and sanity only, the numbers live in profiles/
+    spd = os.path.join(os.path.dirname(exe), "speed_blockqr")
+    if not os.path.exists(spd):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "speed_blockqr"])
+    out = subprocess.run([spd, "65536", "64", "2"], capture_output=True, text=True, timeout=300)
+    lines = out.stdout.strip().split("\n")
+    assert out.returncode == 0 and len(lines) == 4 and lines[1].startswith("65536,64,1,float,fp32_tc_cor,0,"), out.stdout + out.stderr
+    assert all(float(l.split(",")[6]) > 0 for l in lines[1:])
 
 
 @pytest.mark.parametrize("policy", ["householder", "gram_f64", "gram_bf16"])
