@@ -1027,6 +1027,7 @@ struct ApplyArgs {
 	const float* z;                     // NP x NP, ld NP
 	int nchunks; int cpw; int nwaves;
 	int n_out;                          // UPD only: columns of the output / C input (n is then the contraction length, 64)
+	double* gpart;                      // GRAMQ only: per-workgroup partial Gram tiles of the OUTPUT block rows (format of gram_bf16_kernel)
 	const unsigned* skip_status;        // optional: the kernel returns at once when *skip_status != 0 (the Cholesky kernel
 	                                    // rejected its Gram matrix: a speculatively enqueued apply then costs a launch, not a pass)
 };
@@ -1047,8 +1048,10 @@ struct ApplyArgs {
 // correction terms (range and precision of fp16, like the reference's mode).
 // ApplyArgs: nchunks = number of row blocks, nwaves = number of workgroups, cpw unused.
 // ---------------------------------------------------------------------------------------------
-template <int ENGINE, int NT, bool UPD, int ROWS>
-__global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
+// GRAMQ: additionally accumulate the Gram matrix Q^T Q of the rows this workgroup produces (bf16-split level, fp64 totals, same
+// partial format as gram_bf16_kernel) -- the second sweep of a reorthogonalisation then needs no Gram pass of its own.
+template <int ENGINE, int NT, bool UPD, int ROWS, bool GRAMQ>
+__device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	constexpr int NP = 16 * NT;
 	constexpr int RS = ROWS + 4;                         // column stride of As (floats)
 	constexpr int LPC = ROWS / 4, CPI = 64 / LPC;        // lanes per column, columns per load instruction
@@ -1097,6 +1100,12 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 		}
 	};
 
+	constexpr int NTRI = (NT * (NT + 1)) / 2;
+	f64x4 gtot[GRAMQ ? NTRI : 1];
+	if constexpr (GRAMQ) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++) gtot[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+	}
 	// the first block's loads are issued before Z is staged: their HBM latency overlaps the staging work
 	f32x4 v[NI];
 	int bi = blockIdx.x;
@@ -1254,6 +1263,51 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 				*reinterpret_cast<f32x4*>(&As[col * RS + ((rb + 4 * q) ^ swz(col))]) = acc[ct];
 			}
 		}
+		if constexpr (GRAMQ) {
+			// Gram tiles of this wave's freshly written rows (ROWS/4 rows = ROWS/128 K-steps of 32): lane (c,q) reads logical rows
+			// 8q..8q+7 of column 16t+c (two 16-byte reads; the XOR swizzle keeps 8-row groups contiguous), one MFMA chain from zero per
+			// K-step, added to fp64 totals -- exactly gram_bf16_kernel's arithmetic on the values that are about to be stored
+#pragma unroll
+			for (int ks = 0; ks < ROWS / 128; ks++) {
+				const int rbk = wv * (ROWS / 4) + 32 * ks + 8 * q;
+				bf16x8 oh[NT], om[NT], ol[NT];
+#pragma unroll
+				for (int t = 0; t < NT; t++) {
+					const int col = 16 * t + c;
+					const f32x4 x0 = *reinterpret_cast<const f32x4*>(&As[col * RS + (rbk ^ swz(col))]);
+					const f32x4 x1 = *reinterpret_cast<const f32x4*>(&As[col * RS + ((rbk + 4) ^ swz(col))]);
+					u32x4 hh, mm, ll;
+					unsigned h, m, lo;
+					split3_pair(x0[0], x0[1], h, m, lo); hh[0] = h; mm[0] = m; ll[0] = lo;
+					split3_pair(x0[2], x0[3], h, m, lo); hh[1] = h; mm[1] = m; ll[1] = lo;
+					split3_pair(x1[0], x1[1], h, m, lo); hh[2] = h; mm[2] = m; ll[2] = lo;
+					split3_pair(x1[2], x1[3], h, m, lo); hh[3] = h; mm[3] = m; ll[3] = lo;
+					oh[t] = __builtin_bit_cast(bf16x8, hh);
+					om[t] = __builtin_bit_cast(bf16x8, mm);
+					ol[t] = __builtin_bit_cast(bf16x8, ll);
+				}
+				f32x4 gacc[NTRI];
+#pragma unroll
+				for (int t = 0; t < NTRI; t++) gacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int pass = 3; pass < 9; pass++) {       // mm hl lh hm mh hh (smallest first), as in gram_bf16_kernel
+					int idx = 0;
+#pragma unroll
+					for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+						for (int tj = ti; tj < NT; tj++) {
+							const bf16x8 av = (pass == 4 || pass == 6 || pass == 8) ? oh[ti] : ((pass == 3 || pass == 7) ? om[ti] : ol[ti]);
+							const bf16x8 bv = (pass == 5 || pass == 7 || pass == 8) ? oh[tj] : ((pass == 3 || pass == 6) ? om[tj] : ol[tj]);
+							gacc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, gacc[idx], 0, 0, 0);
+							idx++;
+						}
+				}
+#pragma unroll
+				for (int t = 0; t < NTRI; t++)
+#pragma unroll
+					for (int r = 0; r < 4; r++) gtot[t][r] += (double)gacc[t][r];
+			}
+		}
 		__syncthreads();
 		{
 			const size_t row = (size_t)b * ROWS + lrow;
@@ -1281,6 +1335,48 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 		}
 		__syncthreads();
 	}
+	if constexpr (GRAMQ) {
+		// workgroup sum in fp64 (LDS aliases As / the Z image: every wave has passed the loop's last barrier), as in gram_bf16_kernel
+		double* red = reinterpret_cast<double*>(smem);   // [2][NTRI*256]
+		if (wv >= 2) {
+#pragma unroll
+			for (int t = 0; t < NTRI; t++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) red[(size_t)(wv - 2) * NTRI * 256 + (t * 4 + r) * 64 + lane] = gtot[t][r];
+		}
+		__syncthreads();
+		if (wv < 2) {
+#pragma unroll
+			for (int t = 0; t < NTRI; t++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) gtot[t][r] += red[(size_t)wv * NTRI * 256 + (t * 4 + r) * 64 + lane];
+		}
+		__syncthreads();
+		if (wv == 1) {
+#pragma unroll
+			for (int t = 0; t < NTRI; t++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) red[(t * 4 + r) * 64 + lane] = gtot[t][r];
+		}
+		__syncthreads();
+		if (wv == 0) {
+			double* out = a.gpart + (size_t)blockIdx.x * NTRI * 256;
+#pragma unroll
+			for (int t = 0; t < NTRI; t++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = gtot[t][r] + red[(t * 4 + r) * 64 + lane];
+		}
+	}
+}
+
+template <int ENGINE, int NT, bool UPD, int ROWS, bool GRAMQ = false>
+__global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
+	apply_wg_body<ENGINE, NT, UPD, ROWS, false>(a);
+}
+// the variant that also accumulates Q^T Q: two waves per SIMD (the register allocator is told to stay within 256 registers)
+template <int ENGINE, int NT, bool UPD, int ROWS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void apply_wg_gramq_kernel(const ApplyArgs a) {
+	apply_wg_body<ENGINE, NT, UPD, ROWS, true>(a);
 }
 
 // R <- R2 * R1 (n x n upper triangular, fp64 accumulation).  r1 is a packed copy (ld n) of the old R.

@@ -54,6 +54,10 @@ struct HostSig { unsigned* host = nullptr; unsigned* dev = nullptr; };
 HostSig g_hsig;
 int g_shifted = env_int("TSQR_MI_SHIFTED", 1);         // shifted Cholesky QR (two-step) before the Householder fallback
 bool g_used_shift = false, g_used_householder = false;
+int g_fuse_gramq = env_int("TSQR_MI_FUSE_GRAMQ", 1);   // reorthogonalisation, n <= 64: the first sweep's apply kernel also accumulates Q^T Q
+double* g_gramq_part = nullptr;                         // non-null: apply launches write per-workgroup Gram partials of their output there
+int g_gramq_cap = 0, g_gramq_nparts = 0;               // capacity of that buffer (workgroups), workgroups of the last fused launch
+bool g_gramq_ready = false;                             // the next bf16-level Gram request can skip its pass (partials are in place)
 int g_reduce1 = env_int("TSQR_MI_REDUCE1", 1);         // partials -> G in one launch (gram_reduce1_kernel) instead of two
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
@@ -243,7 +247,10 @@ int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float*
 	a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
 	a.part = reinterpret_cast<double*>(wr);
 	int nparts = g.nblocks;                              // workgroups that wrote a partial
-	{
+	if (bf16 && g_gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
+		g_gramq_ready = false;
+		nparts = g_gramq_nparts;
+	} else {
 		ProfScope ps(KC_GRAM, st);
 		switch (NT) {
 			case 1: nparts = launch_gram<1>(a, g.nblocks, bf16, st); break;
@@ -295,14 +302,20 @@ int gram_r(float* r, size_t ldr, float* z_buf, const float* src, size_t ld, size
 }
 
 // apply_wg_kernel launcher: args.nchunks = row blocks of ROWS, args.nwaves = workgroups (persistent grid)
-template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyArgs a, hipStream_t st) {
+template <int E, int NT, bool UPD, int ROWS, bool GRAMQ> constexpr auto apply_wg_entry() {
+	if constexpr (GRAMQ) return &tsqrmi::apply_wg_gramq_kernel<E, NT, UPD, ROWS>;
+	else return &tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>;
+}
+template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_apply_wg(tsqrmi::ApplyArgs a, hipStream_t st) {
+	constexpr auto kernel = apply_wg_entry<E, NT, UPD, ROWS, GRAMQ>();
 	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
 	constexpr int NB = (!UPD && NT == 4) ? 6 : KT * NT;  // operand blocks of Z kept in LDS (apply_wg_kernel: COMPACT)
-	const size_t lds = sizeof(float) * NP * (ROWS + 4) +
-	                   (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)(E == 2 ? 1 : 3) * NB * 512 * 2);
+	size_t lds = sizeof(float) * NP * (ROWS + 4) +
+	             (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)(E == 2 ? 1 : 3) * NB * 512 * 2);
+	if (GRAMQ) lds = std::max(lds, sizeof(double) * 2 * (NT * (NT + 1) / 2) * 256);   // the final workgroup reduction aliases the block
 	static bool attr_done = false;
 	if (!attr_done) {
-		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>),
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
 		                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		attr_done = true;
 	}
@@ -312,17 +325,25 @@ template <int E, int NT, bool UPD, int ROWS> int launch_apply_wg(tsqrmi::ApplyAr
 	static int per_cu = 0;
 	if (per_cu == 0) {
 		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>),
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel),
 		                                                 256, lds) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 2; }
 		per_cu = std::min(nb, E == 0 ? 2 : 3);           // measured: the fp32-MFMA engine is slower with three per CU (132 vs 112 us)
 	}
 	const size_t want = g_apply_wgs > 0 ? (size_t)g_apply_wgs : (size_t)256 * per_cu;
 	a.nwaves = (int)std::min<size_t>(nblk, want);
 	a.cpw = 0;
-	hipLaunchKernelGGL((tsqrmi::apply_wg_kernel<E, NT, UPD, ROWS>), dim3(a.nwaves), dim3(256), lds, st, a);
+	if constexpr (GRAMQ) {
+		a.nwaves = std::min(a.nwaves, g_gramq_cap);      // one partial per workgroup: never more than the buffer holds
+		a.gpart = g_gramq_part;
+		g_gramq_nparts = a.nwaves;
+	}
+	hipLaunchKernelGGL(kernel, dim3(a.nwaves), dim3(256), lds, st, a);
 	return 0;
 }
 template <int E, int NT, bool UPD> int launch_apply_any(const tsqrmi::ApplyArgs& a, hipStream_t st) {
+	if constexpr (!UPD) {
+		if (g_gramq_part && g_gramq_cap > 0) return launch_apply_wg<E, NT, UPD, 128, true>(a, st);
+	}
 	if (g_apply_rows == 256) return launch_apply_wg<E, NT, UPD, 256>(a, st);
 	return launch_apply_wg<E, NT, UPD, 128>(a, st);
 }
@@ -643,9 +664,16 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 			// the work buffer (packed, ld n); every sweep writes their upper triangles in full and rmul_kernel reads nothing else,
 			// so neither needs zero-filling, and the product is written straight into the caller's r (zeros below the diagonal)
 			float* r1 = wq + L.r1; float* r2 = wq + L.r2;
+			// single panel: the first sweep's (last) apply launch accumulates Q^T Q while the block is in LDS, so that the second
+			// sweep's bf16-level Gram pass over Q is not needed
+			const bool fuse = g_fuse_gramq && n <= PW && g_policy == 0 && level == 2;
+			if (fuse) { g_gramq_part = reinterpret_cast<double*>(wr); g_gramq_cap = gram_plan(m, n).nblocks; g_gramq_nparts = 0; }
 			rc = sweep(engine, level, check_now, q, ldq, r1, n, a, lda, m, n, wq, wr, L, h_wl, st);
+			g_gramq_part = nullptr; g_gramq_cap = 0;
 			if (rc) return rc;
+			g_gramq_ready = fuse && g_gramq_nparts > 0;
 			rc = sweep(engine, level, check_now, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
+			g_gramq_ready = false;
 			if (rc) return rc;
 			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
 		}
