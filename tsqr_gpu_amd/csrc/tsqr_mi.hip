@@ -341,7 +341,7 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 	return 0;
 }
 template <int E, int NT, bool UPD> int launch_apply_any(const tsqrmi::ApplyArgs& a, hipStream_t st) {
-	if constexpr (!UPD) {
+	if constexpr (!UPD && E != 0) {                      // (the fp32-MFMA engine's fused variant spills and loses: 0.29 vs 0.22 ms per apply)
 		if (g_gramq_part && g_gramq_cap > 0) return launch_apply_wg<E, NT, UPD, 128, true>(a, st);
 	}
 	if (g_apply_rows == 256) return launch_apply_wg<E, NT, UPD, 256>(a, st);
