@@ -24,8 +24,8 @@ extern "C" {
 enum tsqr_mi_compute_mode {
 	TSQR_MI_FP16_NOTC = 0,
 	TSQR_MI_FP16_TC_NOCOR = 1,
-	TSQR_MI_FP32_NOTC = 2,         /* supported: exact fp32 (VALU + v_mfma_f32_16x16x4_f32) */
-	TSQR_MI_FP32_TC_COR = 3,       /* supported: bf16 MFMA with 3-way split error correction */
+	TSQR_MI_FP32_NOTC = 2,         /* supported: Q = A*inverse(R) on exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+	TSQR_MI_FP32_TC_COR = 3,       /* supported: Q = A*inverse(R) on bf16 MFMA with 3-way split error correction (six products) */
 	TSQR_MI_FP32_TC_NOCOR = 4,     /* supported: R as fp32_tc_cor; Q = A*inverse(R) on fp16 MFMA, one product, no correction */
 	TSQR_MI_MIXED_TC_COR_EMU = 5,
 	TSQR_MI_TF32_TC_COR = 6,       /* no xf32 MFMA on gfx950: unsupported */
@@ -118,10 +118,12 @@ void tsqr_mi_profile_enable(int on);
 int tsqr_mi_profile_read(double* ms, long* launches, int max_classes);
 
 /* R-factor engine policy (Q is always formed by apply: Q = A * inverse(R) on the MFMA units).
- *   0 auto (default): fp32_notc -> Householder TSQR (fp32 arithmetic only).
- *                     fp32_tc_cor -> Gram engine, R = chol(A^T A):  first the bf16x3-split MFMA Gram matrix (memory-bound),
- *                     accepted when every Cholesky pivot keeps >= 2^-5 of its diagonal entry (nearly orthogonal columns);
- *                     else the fp64-MFMA Gram matrix, accepted down to 2^-40 (cond(A) up to ~1e6); else Householder TSQR.
+ *   0 auto (default), every mode: Gram engine, R = chol(A^T A).  First the bf16x3-split MFMA Gram matrix (exact products, fp64
+ *                     accumulation across K-steps, memory-bound), accepted when every Cholesky pivot keeps >= 2^-5 of its diagonal
+ *                     entry and the scaled conditioning S = ||D inverse(R)||_F^2 / n stays below min(128, max(4, 0.12 sqrt(rows)));
+ *                     else the fp64-MFMA Gram matrix, accepted down to a pivot ratio of 2^-40 (cond(A) up to ~1e6); else the
+ *                     shifted Cholesky QR step on that fp64 Gram matrix + one plain fp64 sweep in place; Householder TSQR last.
+ *                     The compute mode selects the MFMA engine of the apply pass (exact fp32 / bf16x3 split / single fp16 product).
  *   1 always Householder TSQR.   2 always fp64 Gram (no fallback).   3 always bf16-split Gram (no check; tests only).
  *   4 auto without the bf16-split level.
  * tsqr_mi_last_engine(): 0 Householder, 1 fp64 Gram, 2 Gram rejected -> Householder, 3 bf16-split Gram,
