@@ -395,12 +395,15 @@ struct GramArgs {
 	const float* a; size_t lda; size_t m; int n;
 	int nchunks; int cpw; int nwaves;
 	double* part;                        // [gridDim.x][NTRI][256]  (tile, lane, reg) order of the MFMA accumulators
+	const unsigned* skip_status;         // optional: return at once when *skip_status != 0 (an earlier, speculatively enqueued
+	                                     // sweep this pass depends on was rejected; its successor Cholesky reports "rejected" too)
 };
 
 template <int NT>
 __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
+	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	const int gw = blockIdx.x * 4 + wv;
@@ -480,6 +483,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
+	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	const int gw = blockIdx.x * 4 + wv;
@@ -863,7 +867,17 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 
 __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                                    const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio,
-                                                   float max_scond, unsigned* __restrict__ host_status, double shift_coef) {
+                                                   float max_scond, unsigned* __restrict__ host_status, double shift_coef,
+                                                   const unsigned* __restrict__ prev_status) {
+	// prev_status: status word of an earlier factorisation this one depends on (speculatively enqueued second sweep): when that one
+	// was rejected this one reports "rejected" at once, so that everything enqueued behind it skips as well
+	if (prev_status && prev_status[0] != 0) {
+		if (threadIdx.x == 0) {
+			status[0] = 1u; status[1] = 0u; status[2] = 0u;
+			if (host_status) { volatile unsigned* hs = host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
+		}
+		return;
+	}
 	chol_body(r, ldr, z, status, host_status, [&](int e) { return gsum[e]; }, n, NT, f32_layout, min_ratio, max_scond, shift_coef);
 }
 

@@ -58,6 +58,8 @@ int g_fuse_gramq = env_int("TSQR_MI_FUSE_GRAMQ", 1);   // reorthogonalisation, n
 double* g_gramq_part = nullptr;                         // non-null: apply launches write per-workgroup Gram partials of their output there
 int g_gramq_cap = 0, g_gramq_nparts = 0;               // capacity of that buffer (workgroups), workgroups of the last fused launch
 bool g_gramq_ready = false;                             // the next bf16-level Gram request can skip its pass (partials are in place)
+int g_spec_reorth = env_int("TSQR_MI_SPEC_REORTH", 1);   // reorthogonalisation, n <= 64: both sweeps enqueued speculatively (status slots, device-side skips)
+int g_slot = 0, g_prev_slot = -1;                      // status slot of the sweep being enqueued / of the sweep it depends on (-1: none)
 int g_reduce1 = env_int("TSQR_MI_REDUCE1", 1);         // partials -> G in one launch (gram_reduce1_kernel) instead of two
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
@@ -246,6 +248,7 @@ int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float*
 	tsqrmi::GramArgs a{};
 	a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
 	a.part = reinterpret_cast<double*>(wr);
+	a.skip_status = g_prev_slot >= 0 ? reinterpret_cast<const unsigned*>(wq + L.status) + 16 * g_prev_slot : nullptr;
 	int nparts = g.nblocks;                              // workgroups that wrote a partial
 	if (bf16 && g_gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		g_gramq_ready = false;
@@ -283,10 +286,12 @@ int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t r
 	const int NT = (int)(np_of(n) / 16);
 	{
 		ProfScope ps(KC_CHOL, st);
+		unsigned* sdev = reinterpret_cast<unsigned*>(wq + L.status) + 16 * g_slot;
+		const unsigned* sprev = g_prev_slot >= 0 ? reinterpret_cast<const unsigned*>(wq + L.status) + 16 * g_prev_slot : nullptr;
 		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
-		                   reinterpret_cast<unsigned*>(wq + L.status), gsum, (int)n, NT, bf16 ? 1 : 0,
+		                   sdev, gsum, (int)n, NT, bf16 ? 1 : 0,
 		                   shift_coef > 0.0 ? 0.0f : (bf16 ? 0.03125f : 9.094947017729282e-13f),
-		                   bf16 ? bf16_scond_limit(rows) : INFINITY, host_status, shift_coef);
+		                   bf16 ? bf16_scond_limit(rows) : INFINITY, host_status ? host_status + 4 * g_slot : nullptr, shift_coef, sprev);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -417,6 +422,7 @@ int engine_of(int mode) {
 	return -1;
 }
 
+int signal_and_wait(hipStream_t st);
 // read the Gram engine's status word (0 ok / 1 breakdown) after draining the stream
 int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStream_t st, unsigned* out) {
 	if (g_debug) {
@@ -427,8 +433,10 @@ int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStrea
 		memcpy(&ratio, &w3[1], 4); memcpy(&scond, &w3[2], 4);
 		fprintf(stderr, "[tsqr_mi] chol status %u  min pivot ratio %.4g  scaled cond S %.4g\n", w3[0], ratio, scond);
 	}
-	if (h_pinned && h_pinned == g_hsig.host && g_hsig.dev) {      // gram_finish_kernel already wrote the words to h_wl
-		HIPCHK(hipStreamSynchronize(st));
+	if (h_pinned && h_pinned == g_hsig.host && g_hsig.dev) {      // the Cholesky kernel wrote the words to h_wl itself
+		const int w = signal_and_wait(st);                   // spin on the completion flag (no OS wake-up in the path), else a stream sync
+		if (w < 0) return w;
+		if (w == 1) HIPCHK(hipStreamSynchronize(st));
 		*out = reinterpret_cast<volatile unsigned*>(h_pinned)[0];
 		return 0;
 	}
@@ -471,7 +479,7 @@ int panel_qr(int engine, int r_engine, bool check_now, float* qp, size_t ldq, fl
 		if (ok) {
 			g_min_level = std::min(g_min_level, e);
 			// speculative (unchecked) launch under the auto policy: the kernel itself skips the pass when the level was rejected
-			const unsigned* skip = (!check_now && g_policy == 0) ? reinterpret_cast<const unsigned*>(wq + L.status) : nullptr;
+			const unsigned* skip = (!check_now && g_policy == 0) ? reinterpret_cast<const unsigned*>(wq + L.status) + 16 * g_slot : nullptr;
 			return apply_rinv(engine, qp, ldq, ap, lda, rpp, ldr, m, c, wq + L.z, st, /*z_ready=*/true, skip);
 		}
 	}
@@ -667,12 +675,60 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 			// single panel: the first sweep's (last) apply launch accumulates Q^T Q while the block is in LDS, so that the second
 			// sweep's bf16-level Gram pass over Q is not needed
 			const bool fuse = g_fuse_gramq && n <= PW && g_policy == 0 && level == 2;
-			if (fuse) { g_gramq_part = reinterpret_cast<double*>(wr); g_gramq_cap = gram_plan(m, n).nblocks; g_gramq_nparts = 0; }
+			if (g_spec_reorth && n <= PW && g_policy == 0 && level == first_level && !g_prof.on) {
+				// Optimistic attempt: both sweeps, the R product and the completion flag are enqueued without looking at a verdict.
+				// Device-side chain: apply 1 skips when Cholesky 1 rejected; Cholesky 2 then reports "rejected" at once; apply 2 (in
+				// place) skips when Cholesky 2 rejected -- so A stays intact and Q holds Q1 or garbage, never a half-applied state.
+				if (fuse) { g_gramq_part = reinterpret_cast<double*>(wr); g_gramq_cap = gram_plan(m, n).nblocks; g_gramq_nparts = 0; }
+				g_slot = 0; g_prev_slot = -1;
+				rc = sweep(engine, level, /*check_now=*/false, q, ldq, r1, n, a, lda, m, n, wq, wr, L, h_wl, st);
+				g_gramq_part = nullptr; g_gramq_cap = 0;
+				if (!rc) {
+					g_gramq_ready = fuse && g_gramq_nparts > 0;
+					g_slot = 1; g_prev_slot = 0;
+					rc = sweep(engine, level, /*check_now=*/false, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
+					g_gramq_ready = false;
+				}
+				g_slot = 0; g_prev_slot = -1;
+				if (rc) return rc;
+				hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
+				HIPCHK(hipGetLastError());
+				unsigned s01[2] = {1u, 1u};
+				rc = signal_and_wait(st);
+				if (rc < 0) return rc;
+				if (rc == 0) {
+					s01[0] = reinterpret_cast<volatile unsigned*>(g_hsig.host)[0];
+					s01[1] = reinterpret_cast<volatile unsigned*>(g_hsig.host)[4];
+				} else {
+					HIPCHK(hipStreamSynchronize(st));
+					unsigned w[17];
+					HIPCHK(hipMemcpy(w, wq + L.status, sizeof(w), hipMemcpyDeviceToHost));
+					s01[0] = w[0]; s01[1] = w[16];
+				}
+				if (s01[0] == 0 && s01[1] == 0) break;       // both sweeps accepted: done (g_min_level was set by panel_qr)
+				g_min_level = 2;
+				if (s01[0] == 0) {
+					// the first sweep stands (Q holds Q1, r1 is valid); only the second one must be redone, now checked and below
+					// the level that was just rejected
+					rc = sweep(engine, level - 1, /*check_now=*/true, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
+					if (rc) return rc;
+					g_min_level = std::min(g_min_level, level);  // (first sweep ran at `level`)
+					hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
+					HIPCHK(hipGetLastError());
+					rc = signal_and_wait(st);
+					if (rc < 0) return rc;
+					if (rc == 1) HIPCHK(hipStreamSynchronize(st));
+					break;
+				}
+				level = std::max(level - 1, 0);              // first sweep rejected at this level: checked path from the next one
+			}
+			const bool fuse2 = g_fuse_gramq && n <= PW && g_policy == 0 && first_level == 2;
+			if (fuse2) { g_gramq_part = reinterpret_cast<double*>(wr); g_gramq_cap = gram_plan(m, n).nblocks; g_gramq_nparts = 0; }
 			rc = sweep(engine, level, check_now, q, ldq, r1, n, a, lda, m, n, wq, wr, L, h_wl, st);
 			g_gramq_part = nullptr; g_gramq_cap = 0;
 			if (rc) return rc;
-			g_gramq_ready = fuse && g_gramq_nparts > 0;
-			rc = sweep(engine, level, check_now, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
+			g_gramq_ready = fuse2 && g_gramq_nparts > 0;     // the second sweep always starts at the first level again (Q1 is well conditioned)
+			rc = sweep(engine, first_level, check_now, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
 			g_gramq_ready = false;
 			if (rc) return rc;
 			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
