@@ -92,6 +92,8 @@ int tsqr_mi_chol_f32(int level, float* r, size_t ldr, const double* gsum, size_t
  * status_out == NULL above: asynchronous (no stream sync); the verdict is then read with tsqr_mi_chol_status (blocking) -- lets a
  * caller enqueue tsqr_mi_apply_z_f32 speculatively behind the Cholesky and pay one synchronisation per sweep. */
 int tsqr_mi_chol_status(const void* wq, size_t m, size_t n, unsigned* status_out, void* stream);
+/* blocks until everything enqueued on `stream` so far has completed (spin on a pinned completion word; stream sync as fallback) */
+int tsqr_mi_stream_wait(void* stream);
 int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t lda, size_t m, size_t n, void* wq, void* stream);
 /* r (n x n) <- r2 * r (upper triangular product, used after a reorthogonalisation sweep) */
 int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t n, void* wq, void* stream);

@@ -43,7 +43,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_qr_f32", "tsqr_mi_local_r_f32", "tsqr_mi_apply_rinv_f32", "tsqr_mi_rmul_f32",
     "tsqr_mi_qr_f32_dist", "tsqr_mi_set_tuning", "tsqr_mi_profile_enable", "tsqr_mi_profile_read",
     "tsqr_mi_set_policy", "tsqr_mi_last_engine", "tsqr_mi_set_tuning2",
-    "tsqr_mi_gram_elems", "tsqr_mi_gram_f32", "tsqr_mi_chol_f32", "tsqr_mi_chol_status", "tsqr_mi_apply_z_f32", "tsqr_mi_validate_f32",
+    "tsqr_mi_gram_elems", "tsqr_mi_gram_f32", "tsqr_mi_chol_f32", "tsqr_mi_chol_status", "tsqr_mi_stream_wait", "tsqr_mi_apply_z_f32", "tsqr_mi_validate_f32",
 ]
 
 _lib = None
@@ -84,6 +84,8 @@ def lib():
     L.tsqr_mi_chol_f32.argtypes = [ci, vp, sz, vp, sz, sz, vp, ctypes.POINTER(ctypes.c_uint), vp]
     L.tsqr_mi_chol_status.restype = ci
     L.tsqr_mi_chol_status.argtypes = [vp, sz, sz, ctypes.POINTER(ctypes.c_uint), vp]
+    L.tsqr_mi_stream_wait.restype = ci
+    L.tsqr_mi_stream_wait.argtypes = [vp]
     L.tsqr_mi_apply_z_f32.restype = ci
     L.tsqr_mi_apply_z_f32.argtypes = [ci, vp, sz, vp, sz, sz, sz, vp, vp]
     L.tsqr_mi_validate_f32.restype = ci

@@ -45,6 +45,7 @@ float bf16_scond_limit(size_t rows) {
 	return std::min(128.0f, std::max(g_bf16_max_scond, 0.12f * sqrtf((float)rows)));
 }
 int g_debug = env_int("TSQR_MI_DEBUG", 0);
+unsigned g_seq = 0;                                   // sequence number of the completion flags
 int g_host_status = env_int("TSQR_MI_HOST_STATUS", 1);   // Cholesky status words written straight into the pinned h_wl
 int g_host_flag = env_int("TSQR_MI_HOST_FLAG", 1);       // end of call: spin on a pinned flag word instead of hipStreamSynchronize
 // The Cholesky kernel also writes its status words (status, min pivot ratio, scaled cond) straight into the caller's pinned
@@ -395,7 +396,6 @@ void resolve_host_sig(unsigned* h_wl) {
 // End of a call on the fast path: a one-thread kernel behind the last kernel raises h_wl[3]; the host spins on it (about
 // 5 us cheaper than hipStreamSynchronize, tools/launch_cost.py) and polls the stream now and then so that a failed launch
 // cannot hang the caller.  Returns 1 when the flag path is not available (caller then synchronises the stream).
-unsigned g_seq = 0;
 int signal_and_wait(hipStream_t st) {
 	if (!g_host_flag || !g_hsig.dev || g_prof.on) return 1;
 	unsigned seq = ++g_seq;
@@ -440,9 +440,35 @@ int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStrea
 		*out = reinterpret_cast<volatile unsigned*>(h_pinned)[0];
 		return 0;
 	}
-	if (!h_pinned) {                                     // staged API: a library-owned pinned word (a pageable 4-byte copy costs ~15 us)
+	if (!h_pinned) {                                     // staged API: library-owned pinned words (a pageable 4-byte copy costs ~15 us)
 		static unsigned* own = nullptr;
-		if (!own && hipHostMalloc(reinterpret_cast<void**>(&own), 64, hipHostMallocDefault) != hipSuccess) { own = nullptr; (void)hipGetLastError(); }
+		static unsigned* own_dev = nullptr;
+		if (!own) {
+			if (hipHostMalloc(reinterpret_cast<void**>(&own), 64, hipHostMallocDefault) != hipSuccess) { own = nullptr; (void)hipGetLastError(); }
+			else if (hipHostGetDevicePointer(reinterpret_cast<void**>(&own_dev), own, 0) != hipSuccess) { own_dev = nullptr; (void)hipGetLastError(); }
+		}
+		if (own && own_dev && g_host_flag && !g_prof.on) {
+			// a one-thread kernel copies the status words and raises a flag; the host spins on it (no copy engine, no OS wake-up:
+			// hipStreamSynchronize showed sporadic multi-millisecond stalls on the box, which a rank of a multi-GPU run cannot afford)
+			unsigned seq = ++g_seq;
+			if (seq == 0) seq = ++g_seq;
+			volatile unsigned* flag = own + 3;
+			*flag = 0;
+			hipLaunchKernelGGL(tsqrmi::host_status_flag_kernel, dim3(1), dim3(1), 0, st, own_dev,
+			                   reinterpret_cast<const unsigned*>(wq + L.status), seq);
+			if (hipGetLastError() == hipSuccess) {
+				for (;;) {
+					bool seen = false;
+					for (int i = 0; i < 20000 && !seen; i++) { seen = (*flag == seq); if (!seen) __builtin_ia32_pause(); }
+					if (seen) break;
+					const hipError_t e = hipStreamQuery(st);
+					if (e == hipSuccess) break;
+					if (e != hipErrorNotReady) HIPCHK(e);
+				}
+				*out = reinterpret_cast<volatile unsigned*>(own)[0];
+				return 0;
+			}
+		}
 		h_pinned = own;
 	}
 	if (h_pinned) {
@@ -796,6 +822,37 @@ int tsqr_mi_chol_f32(int level, float* r, size_t ldr, const double* gsum, size_t
 	rc = read_status(wq, L, nullptr, st, &status);       // blocking: the caller decides on the next level
 	if (rc) return rc;
 	*status_out = status;
+	return 0;
+}
+
+// Blocks until everything enqueued on `stream` so far has completed: a one-thread kernel raises a word in library-owned pinned
+// memory and the host spins on it (hipStreamSynchronize as the fallback).  For staged callers that end with an asynchronous call.
+int tsqr_mi_stream_wait(void* stream) {
+	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+	static unsigned* own = nullptr;
+	static unsigned* own_dev = nullptr;
+	if (!own) {
+		if (hipHostMalloc(reinterpret_cast<void**>(&own), 64, hipHostMallocDefault) != hipSuccess) { own = nullptr; (void)hipGetLastError(); }
+		else if (hipHostGetDevicePointer(reinterpret_cast<void**>(&own_dev), own, 0) != hipSuccess) { own_dev = nullptr; (void)hipGetLastError(); }
+	}
+	if (own && own_dev && g_host_flag && !g_prof.on) {
+		unsigned seq = ++g_seq;
+		if (seq == 0) seq = ++g_seq;
+		volatile unsigned* flag = own;
+		*flag = 0;
+		hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, st, own_dev, seq);
+		if (hipGetLastError() == hipSuccess) {
+			for (;;) {
+				bool seen = false;
+				for (int i = 0; i < 20000 && !seen; i++) { seen = (*flag == seq); if (!seen) __builtin_ia32_pause(); }
+				if (seen) return 0;
+				const hipError_t e = hipStreamQuery(st);
+				if (e == hipSuccess) return 0;
+				if (e != hipErrorNotReady) HIPCHK(e);
+			}
+		}
+	}
+	HIPCHK(hipStreamSynchronize(st));
 	return 0;
 }
 

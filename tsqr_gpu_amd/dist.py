@@ -105,6 +105,12 @@ class HipEngine:
             raise RuntimeError("tsqr_mi_chol_f32(shifted) -> %d %s" % (st, bq.last_error()))
         return int(status.value)
 
+    def wait(self):
+        """Block until everything enqueued on the current stream has completed (the single-GPU call is blocking too)."""
+        st = bq.lib().tsqr_mi_stream_wait(self._stream())
+        if st != 0:
+            raise RuntimeError("tsqr_mi_stream_wait -> %d %s" % (st, bq.last_error()))
+
     def apply_z(self, q, ldq, a, lda, m):
         st = bq.lib().tsqr_mi_apply_z_f32(int(self.mode), q.data_ptr(), ldq, a.data_ptr(), lda, m, self.n,
                                           self.wq.data_ptr(), self._stream())
@@ -124,6 +130,7 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
     if world * m_local < n:
         return bq.error_invalid_matrix_size
     src, ld_src = a, lda
+    pending = False                                    # asynchronous work enqueued after the last blocking call?
     for sweep in range(2 if reorthogonalize else 1):
         r_new = None
         r_shift = None
@@ -139,11 +146,13 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
                     # verdict afterwards -- one synchronisation per sweep, no idle gap between the two kernels
                     engine.chol_async(level, g, m_local, r_try)
                     engine.apply_z(q, ldq, src, ld_src, m_local)
-                    ok = engine.chol_status(m_local) == 0
+                    ok = engine.chol_status(m_local) == 0   # (blocking: enqueued behind the apply, so that one is complete too)
+                    pending = False
                 else:
                     ok = engine.chol(level, g, m_local, r_try) == 0
                     if ok:
                         engine.apply_z(q, ldq, src, ld_src, m_local)
+                        pending = True
                 if ok:
                     r_new = r_try
                     engine.last_engine = max(getattr(engine, "last_engine", 0), 3 if level == 2 else 1)
@@ -155,6 +164,7 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
                 r_shift = engine.empty(n, n)
                 if engine.chol_shifted(g, m_local, r_shift) == 0:
                     engine.apply_z(q, ldq, src, ld_src, m_local)
+                    pending = True
                     src, ld_src = q, ldq
                     g = engine.gram(1, q, ldq, m_local)
                     if world > 1:
@@ -181,13 +191,19 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
             else:
                 r_new = r_loc
             engine.apply_rinv(q, ldq, src, ld_src, m_local, r_new)
+            pending = True
         if r_shift is not None:
             engine.rmul(r_shift, r_new)                # R of this sweep = R_second * R1
             r_new = r_shift
+            pending = True
         if sweep == 0:
             if r_new is not r:
                 r.copy_(r_new)
+                pending = True
         else:
             engine.rmul(r, r_new)
+            pending = True
         src, ld_src = q, ldq
+    if pending and hasattr(engine, "wait"):
+        engine.wait()                                  # blocking like mtk::qr::qr: complete on return
     return bq.success_factorization
