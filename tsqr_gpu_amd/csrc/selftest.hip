@@ -61,10 +61,10 @@ int tsqr_selftest_split(float* out, const float* in, int n) { hipLaunchKernelGGL
 extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, const double* gsum, int n, int NT, int reps) {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY, nullptr, 0.0, nullptr);
+	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY, nullptr, 0.0, nullptr, 0.0);
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY, nullptr, 0.0, nullptr);
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY, nullptr, 0.0, nullptr, 0.0);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0.f;

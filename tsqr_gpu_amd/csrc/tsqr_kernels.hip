@@ -754,7 +754,7 @@ __device__ long long g_chol_dbg[32];
 template <class LOADG>
 __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
-                                          float max_scond, double shift_coef = 0.0) {
+                                          float max_scond, double shift_coef = 0.0, double min_diag = 0.0) {
 	__shared__ double Gs[64 * 65];               // symmetric G (assembly only): Gs[row * 65 + col]
 	__shared__ float Rf[64 * 65];                // R rows for the final store
 	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
@@ -840,6 +840,9 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	if (w == 0) {
 		const double d0 = dg[j], p0 = pv[j];
 		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
+		// min_diag (bf16-split level): a column whose squared norm is so small that its fp32 products live near the denormal range
+		// was not accumulated accurately (measured: entries ~1e-22 gave ||Q^T Q - I|| = 1e-2) -> reject, the fp64 level is exact
+		if (j < n && !(d0 >= min_diag)) ratio = 0.0f;
 		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
 		if (j == 0) {
 			const float scond = (float)(((Rrow[0] + Rrow[1]) + (Rrow[2] + Rrow[3])) / (double)n);
@@ -868,7 +871,7 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                                    const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio,
                                                    float max_scond, unsigned* __restrict__ host_status, double shift_coef,
-                                                   const unsigned* __restrict__ prev_status) {
+                                                   const unsigned* __restrict__ prev_status, double min_diag) {
 	// prev_status: status word of an earlier factorisation this one depends on (speculatively enqueued second sweep): when that one
 	// was rejected this one reports "rejected" at once, so that everything enqueued behind it skips as well
 	if (prev_status && prev_status[0] != 0) {
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t
 		}
 		return;
 	}
-	chol_body(r, ldr, z, status, host_status, [&](int e) { return gsum[e]; }, n, NT, f32_layout, min_ratio, max_scond, shift_coef);
+	chol_body(r, ldr, z, status, host_status, [&](int e) { return gsum[e]; }, n, NT, f32_layout, min_ratio, max_scond, shift_coef, min_diag);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -292,7 +292,8 @@ int chol_from_g(float* r, size_t ldr, float* z_buf, const double* gsum, size_t r
 		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, st, r, ldr, z_buf,
 		                   sdev, gsum, (int)n, NT, bf16 ? 1 : 0,
 		                   shift_coef > 0.0 ? 0.0f : (bf16 ? 0.03125f : 9.094947017729282e-13f),
-		                   bf16 ? bf16_scond_limit(rows) : INFINITY, host_status ? host_status + 4 * g_slot : nullptr, shift_coef, sprev);
+		                   bf16 ? bf16_scond_limit(rows) : INFINITY, host_status ? host_status + 4 * g_slot : nullptr, shift_coef, sprev,
+		                   bf16 ? (double)rows * 0x1p-90 : 0.0);   // bf16 level: mean squared entry of every column >= 2^-90
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
