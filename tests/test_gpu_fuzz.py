@@ -24,3 +24,13 @@ def test_extreme_input_scales():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(m=1 << 15, n=64, verbose=True) == 0
+
+
+def test_robustness_probes():
+    """Square matrices, columns / rows scaled over 16 / 6 decades, exactly dependent constant columns (bounded, residual at rounding
+    level), non-finite input (returns)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "robust_probe.py")
+    spec = importlib.util.spec_from_file_location("robust_probe", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(verbose=True) == 0

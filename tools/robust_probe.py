@@ -1,0 +1,59 @@
+"""Robustness probes: square matrices, wildly scaled columns / rows, constant columns, non-finite input (must return, not hang)."""
+import sys, os, math
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from tsqr_gpu_amd import blockqr as bq, harness
+
+
+def check(name, a, m, n, mode, reorth, orth_tol, res_tol=2e-6, verbose=True):
+    st, q, r = harness.qr(a.clone(), m, n, mode, reorth)
+    orth = harness.orthogonality_fro(q, m, n)
+    res = harness.residual(q, r, a, m, n)
+    ok = st == 0 and orth < orth_tol and res < res_tol
+    if verbose:
+        print("%s %-34s %5dx%-4d %-12s reorth %d engine %d orth %.2e res %.2e" % ("OK " if ok else "BAD", name, m, n, mode.name, reorth, bq.last_engine(), orth, res), flush=True)
+    return 0 if ok else 1
+
+
+def run(verbose=True):
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    bad = 0
+    modes = (bq.compute_mode.fp32_tc_cor, bq.compute_mode.fp32_notc)
+    for n in (1, 7, 16, 64, 65, 128, 200):                     # square matrices (m == n)
+        a = torch.rand(n, n, generator=g, device="cuda") * 2 - 1
+        cond = harness.get_cond(a, n, n)
+        for mode in modes:
+            bad += check("square", a, n, n, mode, True, max(2e-5, 1e-7 * cond), verbose=verbose)
+    m = 1 << 15
+    for n in (48, 64, 100):
+        base = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
+        cs = torch.logspace(-8, 8, n, device="cuda")[torch.randperm(n, generator=g, device="cuda")]
+        rs = torch.logspace(0, -6, m, device="cuda")
+        for mode in modes:
+            bad += check("columns scaled 1e-8..1e8", base * cs[:, None], m, n, mode, False, 5e-6, verbose=verbose)
+            bad += check("rows scaled 1..1e-6", base * rs[None, :], m, n, mode, True, 5e-6, verbose=verbose)
+        ones = base.clone(); ones[0, :] = 1.0; ones[n // 2, :] = -3.0          # two constant (parallel) columns: rank deficient
+        for mode in modes:
+            st, q, r = harness.qr(ones.clone(), m, n, mode, True)
+            res = harness.residual(q, r, ones, m, n)
+            orth = harness.orthogonality_fro(q, m, n)
+            # exactly dependent columns: the residual stays at rounding level, R shows the deficiency, and all columns of Q but the
+            # dependent one are orthonormal (that one is left un-normalised: ||Q^T Q - I||_F = 1)
+            ok = st == 0 and math.isfinite(res) and res < 2e-6 and orth < 1.01
+            bad += (not ok)
+            if verbose:
+                print("%s %-34s %5dx%-4d %-12s engine %d res %.2e orth %.3f" % ("OK " if ok else "BAD", "two parallel constant columns", m, n, mode.name, bq.last_engine(), res, orth), flush=True)
+    nanm = torch.rand(64, 4096, generator=g, device="cuda"); nanm[3, 100] = float("nan"); nanm[10, 7] = float("inf")
+    for mode in modes:                                           # non-finite input: must come back (state 0, non-finite output), not hang
+        st, q, r = harness.qr(nanm.clone(), 4096, 64, mode, False)
+        ok = st == 0
+        bad += (not ok)
+        if verbose:
+            print("%s non-finite input returns, engine %d, finite Q entries: %d of %d" % ("OK " if ok else "BAD", bq.last_engine(), int(torch.isfinite(q).sum()), q.numel()), flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    b = run()
+    print("bad:", b)
+    sys.exit(1 if b else 0)

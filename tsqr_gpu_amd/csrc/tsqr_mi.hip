@@ -532,10 +532,23 @@ int panel_qr(int engine, int r_engine, bool check_now, float* qp, size_t ldq, fl
 			if (rc) return rc;
 			if (status == 0) {
 				rc = apply_rinv(engine, qp, ldq, qp, ldq, r2, c, m, c, wq + L.z, st, /*z_ready=*/true);
-			} else {                                         // (not observed) finish with the Householder engine on Q1: A = Q (R2' R1) all the same
-				rc = fold_r(r2, c, qp, ldq, m, c, wq, wr, st);
+			} else {
+				// Q1 is still numerically rank deficient: the input has an (almost) exactly dependent column whose rounding residue is
+				// itself dependent (e.g. two constant columns).  No triangular solve can make an orthonormal column out of that; a
+				// second SHIFTED step keeps everything bounded instead -- the other columns come out orthonormal, the residual stays
+				// at rounding level, R shows the deficiency as a tiny diagonal entry and that one column of Q is left un-normalised.
+				rc = chol_from_g(r2, c, wq + L.z, gsum, m, c, wq, L, /*bf16=*/false, st, g_hsig.dev, coef);
 				if (rc) return rc;
-				rc = apply_rinv(engine, qp, ldq, qp, ldq, r2, c, m, c, wq + L.z, st);
+				rc = read_status(wq, L, h_pinned, st, &status);
+				if (rc) return rc;
+				if (status == 0) {
+					rc = apply_rinv(engine, qp, ldq, qp, ldq, r2, c, m, c, wq + L.z, st, /*z_ready=*/true);
+				} else {                                     // non-finite data: last resort, the Householder engine on Q1
+					g_used_householder = true;
+					rc = fold_r(r2, c, qp, ldq, m, c, wq, wr, st);
+					if (rc) return rc;
+					rc = apply_rinv(engine, qp, ldq, qp, ldq, r2, c, m, c, wq + L.z, st);
+				}
 			}
 			if (rc) return rc;
 			const unsigned gbp = (unsigned)std::min<size_t>(1024, cdiv(c * c, 256));
