@@ -39,6 +39,8 @@ class NumpyEngine:
         return 0
 
     def chol_shifted(self, g, m, r):
+        if "s" in self.reject_levels:               # pretend even the shifted factorisation fails (non-finite data on the GPU)
+            return 1
         gm = g.numpy().reshape(self.n, self.n)
         rr = np.linalg.cholesky(gm + 1e-7 * np.trace(gm) * np.eye(self.n)).T
         r.copy_(torch.from_numpy(np.ascontiguousarray(rr.T.astype(np.float32))))
@@ -146,7 +148,9 @@ def test_two_rank_gram_engine_and_escalation():
     assert res["res"] < 1e-6 and res["orth"] < 1e-5 and res["lower"] == 0.0
     res = _run(600, 32, True, use_gram=True, reject=(2,))           # level 2 rejected on every rank -> fp64 level
     assert res["st"] == 0 and res["r_same"] and res["engine"] == 1 and res["orth"] < 1e-5
-    res = _run(600, 32, False, use_gram=True, reject=(2, 1))        # both rejected, also on Q1 -> shifted step + Householder all-gather
+    res = _run(600, 32, False, use_gram=True, reject=(2, 1, "s"))   # nothing Gram-based works -> Householder all-gather path
     assert res["st"] == 0 and res["r_same"] and res["engine"] == 2 and res["orth"] < 1e-5 and res["res"] < 1e-6
+    res = _run(600, 32, False, use_gram=True, reject=(2, 1))        # both rejected, also on Q1 -> two shifted steps
+    assert res["st"] == 0 and res["r_same"] and res["engine"] == 4 and res["orth"] < 1e-4 and res["res"] < 1e-6
     res = _run(600, 32, False, use_gram=True, reject=(2, "1-once")) # both rejected on A, fp64 level fine on Q1 -> shifted Cholesky QR
     assert res["st"] == 0 and res["r_same"] and res["engine"] == 4 and res["orth"] < 1e-5 and res["res"] < 1e-6 and res["lower"] == 0.0

@@ -150,3 +150,19 @@ def test_row_partitioned_driver_ill_conditioned_shifted_path(env, mode):
     assert eng.last_engine == 4
     assert harness.orthogonality_fro(d_q, m, n) < 1e-5 and harness.residual(d_q, d_r, d_a, m, n) < 2e-6
     assert torch.tril(d_r.T, -1).abs().max().item() == 0.0
+
+
+def test_row_partitioned_driver_exactly_dependent_columns(env):
+    """Two constant (parallel) columns through the row-partitioned driver: bounded result, residual at rounding level."""
+    torch, bq, harness, oracle = env
+    from tsqr_gpu_amd import dist as tdist
+    m, n = 1 << 15, 64
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    d_a = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
+    d_a[0, :] = 1.0; d_a[n // 2, :] = -3.0
+    d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+    eng = tdist.HipEngine(bq.compute_mode.fp32_tc_cor, m, n, 1)
+    assert tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=True) == 0
+    torch.cuda.synchronize()
+    assert eng.last_engine == 4
+    assert harness.residual(d_q, d_r, d_a, m, n) < 2e-6 and harness.orthogonality_fro(d_q, m, n) < 1.01

@@ -170,8 +170,11 @@ def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=
                     if world > 1:
                         dist.all_reduce(g, group=group)
                     r2 = engine.empty(n, n)
-                    if engine.chol(1, g, m_local, r2) == 0:
+                    if engine.chol(1, g, m_local, r2) == 0 or engine.chol_shifted(g, m_local, r2) == 0:
+                        # (second alternative: Q1 still numerically rank deficient -- exactly dependent columns -- a second shifted
+                        # step keeps the result bounded, see panel_qr in csrc/tsqr_mi.hip)
                         engine.apply_z(q, ldq, q, ldq, m_local)
+                        pending = True
                         r_new = r2
                         engine.last_engine = 4
                 else:
