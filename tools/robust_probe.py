@@ -43,6 +43,23 @@ def run(verbose=True):
             bad += (not ok)
             if verbose:
                 print("%s %-34s %5dx%-4d %-12s engine %d res %.2e orth %.3f" % ("OK " if ok else "BAD", "two parallel constant columns", m, n, mode.name, bq.last_engine(), res, orth), flush=True)
+    # in place (q aliases a) on inputs that make the first level(s) reject: the speculative launches must leave A intact until a
+    # level is accepted (device-side skip), otherwise the retry would factor garbage
+    for cond in (1e0, 1e4, 1e8):
+        mm, nn = 1 << 15, 64
+        a0 = harness.get_rand_matrix_with_cond_number(mm, nn, cond, seed=11) if cond > 1 else (torch.rand(nn, mm, generator=g, device="cuda") * 2 - 1)
+        for mode in modes:
+            for reorth in (False, True):
+                buf = a0.clone()
+                r = torch.zeros(nn, nn, device="cuda")
+                bf = bq.buffer(mode, reorth); bf.allocate(mm, nn)
+                st = bq.qr(buf, mm, r, nn, buf, mm, mm, nn, bf)
+                res = harness.residual(buf, r, a0, mm, nn)
+                orth = harness.orthogonality_fro(buf, mm, nn)
+                ok = st == 0 and res < 2e-6 and (orth < 2e-5 if (reorth or cond < 10) else orth < 1e-6 * cond * 50)
+                bad += (not ok)
+                if verbose:
+                    print("%s in place cond %-6g %-12s reorth %d engine %d orth %.2e res %.2e" % ("OK " if ok else "BAD", cond, mode.name, reorth, bq.last_engine(), orth, res), flush=True)
     nanm = torch.rand(64, 4096, generator=g, device="cuda"); nanm[3, 100] = float("nan"); nanm[10, 7] = float("inf")
     for mode in modes:                                           # non-finite input: must come back (state 0, non-finite output), not hang
         st, q, r = harness.qr(nanm.clone(), 4096, 64, mode, False)
