@@ -60,6 +60,31 @@ def run(verbose=True):
                 bad += (not ok)
                 if verbose:
                     print("%s in place cond %-6g %-12s reorth %d engine %d orth %.2e res %.2e" % ("OK " if ok else "BAD", cond, mode.name, reorth, bq.last_engine(), orth, res), flush=True)
+    for (mm, nn) in ((20000, 100), (3000, 200)):                 # in place with several panels (a is the workspace of the coupling anyway)
+        a0 = torch.rand(nn, mm, generator=g, device="cuda") * 2 - 1
+        for mode in modes:
+            for reorth in (False, True):
+                buf = a0.clone()
+                r = torch.zeros(nn, nn, device="cuda")
+                bf = bq.buffer(mode, reorth); bf.allocate(mm, nn)
+                st = bq.qr(buf, mm, r, nn, buf, mm, mm, nn, bf)
+                res = harness.residual(buf, r, a0, mm, nn)
+                orth = harness.orthogonality_fro(buf, mm, nn)
+                ok = st == 0 and res < 2e-6 and orth < 2e-5
+                bad += (not ok)
+                if verbose:
+                    print("%s in place %dx%d %-12s reorth %d engine %d orth %.2e res %.2e" % ("OK " if ok else "BAD", mm, nn, mode.name, reorth, bq.last_engine(), orth, res), flush=True)
+    # one buffer allocated for the largest problem serves smaller ones
+    bf = bq.buffer(bq.compute_mode.fp32_tc_cor, True); bf.allocate(1 << 16, 128)
+    for (mm, nn) in ((1 << 16, 128), (5000, 64), (100, 7), (1 << 16, 64)):
+        a0 = torch.rand(nn, mm, generator=g, device="cuda") * 2 - 1
+        q = torch.empty(nn, mm, device="cuda"); r = torch.zeros(nn, nn, device="cuda")
+        st = bq.qr(q, mm, r, nn, a0.clone(), mm, mm, nn, bf)
+        res = harness.residual(q, r, a0, mm, nn); orth = harness.orthogonality_fro(q, mm, nn)
+        ok = st == 0 and res < 2e-6 and orth < 2e-5
+        bad += (not ok)
+        if verbose:
+            print("%s shared buffer %dx%d orth %.2e res %.2e" % ("OK " if ok else "BAD", mm, nn, orth, res), flush=True)
     nanm = torch.rand(64, 4096, generator=g, device="cuda"); nanm[3, 100] = float("nan"); nanm[10, 7] = float("inf")
     for mode in modes:                                           # non-finite input: must come back (state 0, non-finite output), not hang
         st, q, r = harness.qr(nanm.clone(), 4096, 64, mode, False)
