@@ -15,6 +15,7 @@ from tsqr_gpu_amd import blockqr as bq, harness  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--medium", action="store_true", help="the reference's shape family (n = 2^10 .. m) up to m = 2^13")
     ap.add_argument("--count", type=int, default=0, help="matrices per configuration (reference: 16)")
     ap.add_argument("--what", default="accuracy,speed,cond")
     args = ap.parse_args()
@@ -24,6 +25,10 @@ def main():
         C = args.count or 16
         sizes = [(1 << m, 1 << n, 1.0) for m in range(10, 16) for n in range(10, m + 1)]
         conds = [(1 << 15, 1 << 7, float(1 << c)) for c in range(2, 16)]
+    elif args.medium:
+        C = args.count or 2
+        sizes = [(1 << m, 1 << n, 1.0) for m in range(10, 14) for n in range(10, m + 1)]
+        conds = [(1 << 13, 1 << 7, float(1 << c)) for c in (2, 8, 14)]
     else:
         C = args.count or 4
         sizes = [(1 << 12, 1 << 10, 1.0), (1 << 14, 1 << 7, 1.0), (1 << 15, 1 << 10, 1.0), (1 << 20, 64, 1.0)]

@@ -483,6 +483,16 @@ int read_status(const float* wq, const WqLayout& L, unsigned* h_pinned, hipStrea
 	return 0;
 }
 
+// r <- r2 * r1 (upper triangular n x n, fp64 accumulation; r may not alias r1 / r2)
+void launch_rmul(float* r, size_t ldr, const float* r2, size_t ldr2, const float* r1, size_t ldr1, size_t n, hipStream_t st) {
+	if (n > 128) {
+		const unsigned t = (unsigned)cdiv(n, 32);
+		hipLaunchKernelGGL(tsqrmi::rmul_tiled_kernel, dim3(t, t), dim3(256), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
+	} else {
+		const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
+		hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
+	}
+}
 constexpr int R_SHIFT_DIRECT = 9;
 // R factor (and Q) of one <= 64-column panel.  use_gram: Gram/Cholesky engine, otherwise the Householder TSQR engine.
 // check_now: verify the Gram engine's status immediately (one stream sync) and fall back to Householder on breakdown.
@@ -731,7 +741,7 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 				}
 				g_slot = 0; g_prev_slot = -1;
 				if (rc) return rc;
-				hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
+				launch_rmul(r, ldr, r2, n, r1, n, n, st);
 				HIPCHK(hipGetLastError());
 				unsigned s01[2] = {1u, 1u};
 				rc = signal_and_wait(st);
@@ -753,7 +763,7 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 					rc = sweep(engine, level - 1, /*check_now=*/true, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
 					if (rc) return rc;
 					g_min_level = std::min(g_min_level, level);  // (first sweep ran at `level`)
-					hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
+					launch_rmul(r, ldr, r2, n, r1, n, n, st);
 					HIPCHK(hipGetLastError());
 					rc = signal_and_wait(st);
 					if (rc < 0) return rc;
@@ -771,7 +781,7 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 			rc = sweep(engine, first_level, check_now, q, ldq, r2, n, q, ldq, m, n, wq, wr, L, h_wl, st);
 			g_gramq_ready = false;
 			if (rc) return rc;
-			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, n, r1, n, (int)n);
+			launch_rmul(r, ldr, r2, n, r1, n, n, st);
 		}
 		HIPCHK(hipGetLastError());
 		if (level > 0 && deferred) {
