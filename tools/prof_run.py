@@ -1,17 +1,37 @@
 #!/usr/bin/env python3
-"""Small driver for rocprofv3: a few mtk::qr::qr calls at the headline size (2^20 x 64, fp32_tc_cor)."""
-import os, sys
+"""Small driver for rocprofv3: a few mtk::qr::qr calls of one workload.
+usage: prof_run.py [mode] [steps] [--m M] [--n N] [--policy P] [--reorth] [--cond C]
+Defaults: the headline workload (2^20 x 64, fp32_tc_cor, auto policy).  --cond: latms-style matrix with the
+reference's test_cond.cu singular-value draw (harness.get_rand_matrix_with_cond_number)."""
+import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tsqr_gpu_amd import blockqr as bq
-m, n = 1 << 20, 64
-mode = bq.compute_mode[sys.argv[1]] if len(sys.argv) > 1 else bq.compute_mode.fp32_tc_cor
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-g = torch.Generator(device="cuda"); g.manual_seed(0)
-d_a = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
+
+ap = argparse.ArgumentParser()
+ap.add_argument("mode", nargs="?", default="fp32_tc_cor")
+ap.add_argument("steps", nargs="?", type=int, default=5)
+ap.add_argument("--m", type=int, default=1 << 20)
+ap.add_argument("--n", type=int, default=64)
+ap.add_argument("--policy", type=int, default=0)
+ap.add_argument("--reorth", action="store_true")
+ap.add_argument("--cond", type=float, default=0.0)
+args = ap.parse_args()
+m, n = args.m, args.n
+mode = bq.compute_mode[args.mode]
+if args.cond > 0:
+    from tsqr_gpu_amd import harness
+    d_a = harness.get_rand_matrix_with_cond_number(m, n, args.cond, seed=0)
+else:
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    d_a = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
+d_keep = d_a.clone()
 d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
-bf = bq.buffer(mode, False); bf.allocate(m, n)
-for _ in range(steps):
+bf = bq.buffer(mode, args.reorth); bf.allocate(m, n)
+bq.set_policy(args.policy)
+for _ in range(args.steps):
+    if n > 64:
+        d_a.copy_(d_keep)                            # a is overwritten for n > 64
     assert bq.qr(d_q, m, d_r, n, d_a, m, m, n, bf) == 0
 torch.cuda.synchronize()
-print("done")
+print("done engine", bq.ENGINE_NAMES.get(bq.last_engine()))
