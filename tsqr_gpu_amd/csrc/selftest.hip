@@ -72,6 +72,25 @@ extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, c
 	return ms / reps;
 }
 
+// ---- the fp64-MFMA Cholesky / inverse kernel (chol_mfma.hip): one launch (results) or `reps` launches (ms per launch) ----
+extern "C" float tsqr_selftest_chol_mfma(float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT, int f32_layout,
+                                         int level, double rows, double shift_per_row, int reps) {
+	tsqrmi::CholArgs a{};
+	a.r = r; a.ldr = ldr; a.z = z; a.status = status; a.host_status = nullptr; a.gsum = gsum; a.prev_status = nullptr; a.rows_dev = nullptr;
+	a.rows = rows; a.shift_coef_per_row = shift_per_row; a.n = n; a.NT = NT; a.f32_layout = f32_layout; a.level = level; a.scond_floor = 4.0f;
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	tsqrmi::launch_chol_mfma(a, 0);
+	hipEventRecord(e0, 0);
+	for (int i = 0; i < reps; i++) tsqrmi::launch_chol_mfma(a, 0);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0.f;
+	hipEventElapsedTime(&ms, e0, e1);
+	if (hipGetLastError() != hipSuccess) return -1.0f;
+	return reps > 0 ? ms / reps : 0.0f;
+}
+
 #ifdef TSQR_CHOL_DBG
 extern "C" int tsqr_selftest_chol_stamps(long long* out) {
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tsqrmi::g_chol_dbg), sizeof(long long) * 8);
@@ -444,6 +463,86 @@ extern "C" float tsqr_selftest_stream_wg(float* q, const float* a, size_t ld, si
 	(void)hipEventElapsedTime(&ms, e0, e1);
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	return ms / reps;
+}
+
+// ---- a sequence of skeleton passes over the same A / Q, each timed separately (what the two streaming passes of a call can reach
+// when they alternate): pass p = {mode: 0 copy (nt stores) / 1 load only / 2 store only / 3 load only in the per-wave (c,q) chunk pattern,
+// dir: 0 forward / 1 backward block order, nt_load: 1 = nontemporal loads}
+template <int MODE, bool NTL>
+__global__ __launch_bounds__(256) void seq_wg_kernel(float* q, const float* a, size_t ld, size_t m, int nblocks, int nwg, int backward) {
+	constexpr int ROWS = 128, NP = 64;
+	constexpr int LPC = ROWS / 4, CPI = 64 / LPC, NI = NP / (4 * CPI);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
+	tsqrmi::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+	if (MODE == 3) {
+		// per-wave chunks of 64 rows x 64 columns: lane (c,q) loads 16 B of column 16 ct + c at rows 16 rt + 4 q (64-B runs per column and instruction)
+		const int c = lane & 15, qq = lane >> 4;
+		const int nch = (int)(m / 64), gw = blockIdx.x * 4 + wv, nw = nwg * 4;
+		for (int ch0 = gw; ch0 < nch; ch0 += nw) {
+			const int ch = backward ? nch - 1 - ch0 : ch0;
+#pragma unroll
+			for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+				for (int rt = 0; rt < 4; rt++) {
+					const float* src = a + (size_t)(16 * ct + c) * ld + (size_t)ch * 64 + 16 * rt + 4 * qq;
+					acc += NTL ? __builtin_nontemporal_load(reinterpret_cast<const tsqrmi::f32x4u*>(src)) : *reinterpret_cast<const tsqrmi::f32x4u*>(src);
+				}
+		}
+	} else {
+		for (int b0 = blockIdx.x; b0 < nblocks; b0 += nwg) {
+			const int b = backward ? nblocks - 1 - b0 : b0;
+			tsqrmi::f32x4 v[NI];
+#pragma unroll
+			for (int k = 0; k < NI; k++) {
+				const size_t off = (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)b * ROWS + lrow;
+				if (MODE != 2) v[k] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const tsqrmi::f32x4u*>(a + off)) : *reinterpret_cast<const tsqrmi::f32x4u*>(a + off);
+				else v[k] = tsqrmi::f32x4{(float)b, (float)k, 1.f, 2.f};
+			}
+#pragma unroll
+			for (int k = 0; k < NI; k++) {
+				const size_t off = (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)b * ROWS + lrow;
+				if (MODE == 0 || MODE == 2) __builtin_nontemporal_store(v[k], reinterpret_cast<tsqrmi::f32x4u*>(q + off));
+				else acc += v[k];
+			}
+		}
+	}
+	if ((MODE == 1 || MODE == 3) && acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) q[0] = acc[0];
+}
+__global__ void idle_spin_kernel(float* q, int ticks) {       // one wave spinning for ticks x 10 ns (s_memrealtime runs at 100 MHz)
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+	while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+	if (ticks < 0) q[0] = 1.f;
+}
+template <int MODE> static void launch_seq(float* q, const float* a, size_t ld, size_t m, int nwg, int backward, int ntl) {
+	const int nblocks = (int)(m / 128);
+	if (ntl) hipLaunchKernelGGL((seq_wg_kernel<MODE, true>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg, backward);
+	else hipLaunchKernelGGL((seq_wg_kernel<MODE, false>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg, backward);
+}
+extern "C" int tsqr_selftest_seq(float* q, const float* a, size_t ld, size_t m, int nwg, int npass, const int* modes, const int* dirs, const int* ntls,
+                                 int reps, float* out_us) {
+	hipEvent_t ev[2 * 8];
+	if (npass > 8) return -1;
+	for (int i = 0; i < 2 * npass; i++) (void)hipEventCreate(&ev[i]);
+	for (int p = 0; p < npass; p++) out_us[p] = 0.f;
+	for (int it = 0; it < reps + 2; it++) {
+		for (int p = 0; p < npass; p++) {
+			(void)hipEventRecord(ev[2 * p], 0);
+			switch (modes[p]) {
+				case 0: launch_seq<0>(q, a, ld, m, nwg, dirs[p], ntls[p]); break;
+				case 1: launch_seq<1>(q, a, ld, m, nwg, dirs[p], ntls[p]); break;
+				case 2: launch_seq<2>(q, a, ld, m, nwg, dirs[p], ntls[p]); break;
+				case 4: hipLaunchKernelGGL(idle_spin_kernel, dim3(1), dim3(64), 0, 0, q, 100 * dirs[p]); break;   // dirs = microseconds
+				default: launch_seq<3>(q, a, ld, m, nwg, dirs[p], ntls[p]); break;
+			}
+			(void)hipEventRecord(ev[2 * p + 1], 0);
+		}
+		(void)hipDeviceSynchronize();
+		if (it >= 2)
+			for (int p = 0; p < npass; p++) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[2 * p], ev[2 * p + 1]); out_us[p] += ms * 1e3f / reps; }
+	}
+	for (int i = 0; i < 2 * npass; i++) (void)hipEventDestroy(ev[i]);
+	return (int)hipGetLastError();
 }
 
 // ---- achievable v_mfma_f64_16x16x4_f64 rate: 10 independent accumulators per wave, no memory traffic ----

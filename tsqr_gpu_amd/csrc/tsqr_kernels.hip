@@ -391,6 +391,17 @@ __device__ __forceinline__ void split3_pairs(const float (&x)[2 * NPAIR], unsign
 // ---------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// Per-workgroup partial sums are written once and read once a few microseconds later.  Written with plain stores they displace
+// about as many bytes of A from the Infinity Cache, and the apply pass then runs 15 us slower at 2^20 x 64 (tools/mix_bench.py):
+// nontemporal on both sides keeps them out.
+#ifndef TSQR_PART_PLAIN
+__device__ __forceinline__ void part_store(double* p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ double part_load(const double* p) { return __builtin_nontemporal_load(p); }
+#else
+__device__ __forceinline__ void part_store(double* p, double v) { *p = v; }
+__device__ __forceinline__ double part_load(const double* p) { return *p; }
+#endif
+
 struct GramArgs {
 	const float* a; size_t lda; size_t m; int n;
 	int nchunks; int cpw; int nwaves;
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 #pragma unroll
 		for (int t = 0; t < NTRI; t++)
 #pragma unroll
-			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = acc[t][r] + red[0][(t * 4 + r) * 64 + lane];
+			for (int r = 0; r < 4; r++) part_store(&out[(t * 4 + r) * 64 + lane], acc[t][r] + red[0][(t * 4 + r) * 64 + lane]);
 	}
 }
 
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 #pragma unroll
 		for (int t = 0; t < NTRI; t++)
 #pragma unroll
-			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = dacc[t][r] + red[0][(t * 4 + r) * 64 + lane];
+			for (int r = 0; r < 4; r++) part_store(&out[(t * 4 + r) * 64 + lane], dacc[t][r] + red[0][(t * 4 + r) * 64 + lane]);
 	}
 }
 
@@ -638,12 +649,12 @@ __global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ 
 	if (el < nelem) {
 		int b = s;
 		for (; b + 48 < nparts; b += 64) {
-			s0 += part[(size_t)b * nelem + el];
-			s1 += part[(size_t)(b + 16) * nelem + el];
-			s2 += part[(size_t)(b + 32) * nelem + el];
-			s3 += part[(size_t)(b + 48) * nelem + el];
+			s0 += part_load(&part[(size_t)b * nelem + el]);
+			s1 += part_load(&part[(size_t)(b + 16) * nelem + el]);
+			s2 += part_load(&part[(size_t)(b + 32) * nelem + el]);
+			s3 += part_load(&part[(size_t)(b + 48) * nelem + el]);
 		}
-		for (; b < nparts; b += 16) s0 += part[(size_t)b * nelem + el];
+		for (; b < nparts; b += 16) s0 += part_load(&part[(size_t)b * nelem + el]);
 	}
 	red[s][e] = (s0 + s1) + (s2 + s3);
 	__syncthreads();
@@ -1479,3 +1490,5 @@ __global__ __launch_bounds__(256) void zero_lower_kernel(float* __restrict__ r, 
 }
 
 }  // namespace tsqrmi
+#include "chol_mfma.hip"
+#include "gram_dma.hip"

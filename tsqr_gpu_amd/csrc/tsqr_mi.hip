@@ -164,7 +164,7 @@ GramPlan gram_plan(size_t m, size_t n) {
 	g.nwaves = (int)cdiv((size_t)g.nch, (size_t)g.cpw);
 	g.nblocks = (g.nwaves + 3) / 4;
 	g.ntri = (int)(NT * (NT + 1) / 2);
-	g.part_floats = (size_t)g.nblocks * g.ntri * 256 * 2;
+	g.part_floats = (size_t)(g.nblocks + 1) * g.ntri * 256 * 2;   // (+1: the ragged last rows of the LDS-DMA Gram pass go through a one-workgroup launch)
 	return g;
 }
 
@@ -234,10 +234,45 @@ int fold_r(float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n
 	return 0;
 }
 
+int g_gram_dma = env_int("TSQR_MI_GRAM_DMA", 0);       // bf16-level Gram pass: 1 per-wave LDS-DMA bounce (default), 2 workgroup ring, 0 register loads
+inline bool lda_ok(const float* p, size_t ld) { return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0) && ld < ((size_t)1 << 28); }
+template <int NT> void launch_gram_dma(const tsqrmi::GramArgs& a, int grid, hipStream_t st) {
+	constexpr int lds = tsqrmi::GramDmaCfg<NT>::LDS_BYTES;
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_dma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		attr_done = true;
+	}
+	hipLaunchKernelGGL(tsqrmi::gram_dma_kernel<NT>, dim3(grid), dim3(256), lds, st, a);
+}
+template <int NT> void launch_gram_bounce(const tsqrmi::GramArgs& a, int nblocks, hipStream_t st) {
+	constexpr int NTRI = NT * (NT + 1) / 2;
+	constexpr int lds = (4 * NT * 4096 > 2 * NTRI * 256 * 8) ? 4 * NT * 4096 : 2 * NTRI * 256 * 8;
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_bounce_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		attr_done = true;
+	}
+	hipLaunchKernelGGL(tsqrmi::gram_bounce_kernel<NT>, dim3(nblocks), dim3(256), lds, st, a);
+}
 template <int NT> int launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool bf16, hipStream_t st) {
 	if (bf16) hipLaunchKernelGGL(tsqrmi::gram_bf16_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
 	else hipLaunchKernelGGL(tsqrmi::gram_kernel<NT>, dim3(nblocks), dim3(256), 0, st, a);
 	return nblocks;
+}
+
+// the last m % 64 rows of an LDS-DMA Gram pass: one workgroup of gram_bf16_kernel writing partial number `slot`
+int launch_gram_tail(const tsqrmi::GramArgs& a, const float* src, size_t m, int NT, int slot, int ntri, hipStream_t st) {
+	tsqrmi::GramArgs t = a;
+	t.a = src + (m / 64) * 64; t.m = m % 64; t.nchunks = 1; t.cpw = 1; t.nwaves = 1;
+	t.part = a.part + (size_t)slot * ntri * 256;
+	switch (NT) {
+		case 1: launch_gram<1>(t, 1, true, st); break;
+		case 2: launch_gram<2>(t, 1, true, st); break;
+		case 3: launch_gram<3>(t, 1, true, st); break;
+		default: launch_gram<4>(t, 1, true, st); break;
+	}
+	return 1;
 }
 
 // Gram engine: R (n x n, ldr) and Z = inverse(R) (NP x NP in z_buf) of src (m x n); status -> wq[L.status]
@@ -251,9 +286,38 @@ int gram_g(double* gsum, const float* src, size_t ld, size_t m, size_t n, float*
 	a.part = reinterpret_cast<double*>(wr);
 	a.skip_status = g_prev_slot >= 0 ? reinterpret_cast<const unsigned*>(wq + L.status) + 16 * g_prev_slot : nullptr;
 	int nparts = g.nblocks;                              // workgroups that wrote a partial
+	const bool dma_ok = bf16 && g_gram_dma && n % 16 == 0 && m >= 64 && lda_ok(src, ld);
 	if (bf16 && g_gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		g_gramq_ready = false;
 		nparts = g_gramq_nparts;
+	} else if (dma_ok && g_gram_dma == 1) {
+		// per-wave LDS-DMA bounce (gram_dma.hip, gram_bounce_kernel): same geometry and partials as gram_bf16_kernel
+		ProfScope ps(KC_GRAM, st);
+		tsqrmi::GramArgs d = a;
+		d.nchunks = (int)(m / 64);
+		switch (NT) {
+			case 1: launch_gram_bounce<1>(d, g.nblocks, st); break;
+			case 2: launch_gram_bounce<2>(d, g.nblocks, st); break;
+			case 3: launch_gram_bounce<3>(d, g.nblocks, st); break;
+			default: launch_gram_bounce<4>(d, g.nblocks, st); break;
+		}
+		nparts = g.nblocks;
+		if (m % 64) nparts += launch_gram_tail(a, src, m, NT, g.nblocks, g.ntri, st);
+	} else if (dma_ok) {
+		// workgroup-cooperative LDS-DMA pass over the full 64-row blocks (gram_dma.hip), the last m % 64 rows through the per-wave kernel
+		ProfScope ps(KC_GRAM, st);
+		const size_t nblk = m / 64;
+		const int grid = (int)std::min<size_t>(nblk, (size_t)g.nblocks);
+		tsqrmi::GramArgs d = a;
+		d.nchunks = (int)nblk;
+		switch (NT) {
+			case 1: launch_gram_dma<1>(d, grid, st); break;
+			case 2: launch_gram_dma<2>(d, grid, st); break;
+			case 3: launch_gram_dma<3>(d, grid, st); break;
+			default: launch_gram_dma<4>(d, grid, st); break;
+		}
+		nparts = grid;
+		if (m % 64) nparts += launch_gram_tail(a, src, m, NT, grid, g.ntri, st);
 	} else {
 		ProfScope ps(KC_GRAM, st);
 		switch (NT) {
