@@ -1,4 +1,4 @@
-"""GPU tests of the fp64-MFMA Cholesky / inverse kernel (tsqr_gpu_amd/csrc/chol_mfma.hip), the n x n step between the Gram pass and
+"""GPU tests of the pipelined Cholesky / inverse kernel (tsqr_gpu_amd/csrc/chol_wg.hip), the n x n step between the Gram pass and
 the apply pass -- the role of the reference's root tile QR (src/tsqr.cu:1164-1172).  Checked against numpy fp64 Cholesky and
 inverse for both accumulator layouts the Gram kernels produce, ragged n, the shifted variant and the reject paths."""
 import ctypes
@@ -135,5 +135,5 @@ def test_timing_report(st):
     g, _ = spd(64, 3.0, 1)
     for n in (16, 32, 48, 64):
         ms = run(st, g[:n, :n], n, 1, level=2, reps=50)[5]
-        print("chol_mfma_kernel n=%d: %.2f us per launch (back to back)" % (n, ms * 1e3))
+        print("chol_wg_kernel n=%d: %.2f us per launch (back to back)" % (n, ms * 1e3))
     assert ms < 0.05

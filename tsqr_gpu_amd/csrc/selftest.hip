@@ -72,17 +72,17 @@ extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, c
 	return ms / reps;
 }
 
-// ---- the fp64-MFMA Cholesky / inverse kernel (chol_mfma.hip): one launch (results) or `reps` launches (ms per launch) ----
+// ---- the pipelined Cholesky / inverse kernel (chol_wg.hip): one launch (results) or `reps` launches (ms per launch) ----
 extern "C" float tsqr_selftest_chol_mfma(float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT, int f32_layout,
                                          int level, double rows, double shift_per_row, int reps) {
 	tsqrmi::CholArgs a{};
 	a.r = r; a.ldr = ldr; a.z = z; a.status = status; a.host_status = nullptr; a.gsum = gsum; a.prev_status = nullptr; a.rows_dev = nullptr;
-	a.rows = rows; a.shift_coef_per_row = shift_per_row; a.n = n; a.NT = NT; a.f32_layout = f32_layout; a.level = level; a.scond_floor = 4.0f;
+	a.rows = rows; a.shift_coef = shift_per_row; a.n = n; a.NT = NT; a.f32_layout = f32_layout; a.level = level; a.scond_floor = 4.0f;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	tsqrmi::launch_chol_mfma(a, 0);
+	hipLaunchKernelGGL(tsqrmi::chol_wg_kernel, dim3(1), dim3(256), 0, 0, a);
 	hipEventRecord(e0, 0);
-	for (int i = 0; i < reps; i++) tsqrmi::launch_chol_mfma(a, 0);
+	for (int i = 0; i < reps; i++) hipLaunchKernelGGL(tsqrmi::chol_wg_kernel, dim3(1), dim3(256), 0, 0, a);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0.f;
@@ -93,7 +93,7 @@ extern "C" float tsqr_selftest_chol_mfma(float* r, size_t ldr, float* z, unsigne
 
 #ifdef TSQR_CHOL_DBG
 extern "C" int tsqr_selftest_chol_stamps(long long* out) {
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tsqrmi::g_chol_dbg), sizeof(long long) * 8);
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tsqrmi::g_chol_stamps), sizeof(long long) * 4 * 16 * 8);
 }
 #endif
 

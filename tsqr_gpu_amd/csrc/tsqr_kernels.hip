@@ -1490,5 +1490,5 @@ __global__ __launch_bounds__(256) void zero_lower_kernel(float* __restrict__ r, 
 }
 
 }  // namespace tsqrmi
-#include "chol_mfma.hip"
+#include "chol_wg.hip"
 #include "gram_dma.hip"
