@@ -74,50 +74,57 @@ def synth_block(m_local, n, m_global, row0, seed, device):
 
 
 def cpu_baseline(n, mode_name, sample_rows):
-    """Times the CPU oracle (restatement of the reference algorithm, oracle/ref_tsqr.c, OpenMP over leaves) and host
-    LAPACK (scipy) on a bounded sample of the same workload: sample_rows x n, U(-1,1)."""
+    """The reported CPU baseline (north star): host LAPACK sgeqrf + sorgqr (explicit thin Q, F_QR flops -- like for like) on the box's
+    host cores, on a bounded sample of the same workload (sample_rows x n, U(-1,1)); sgeqrf alone (F_R) and the CPU oracle
+    (restatement of the reference algorithm, oracle/ref_tsqr.c, OpenMP over leaves) are nested extras."""
     from oracle import ref_oracle as ro
     a = ro.uniform_matrix(sample_rows, n, seed=0)
+    cores = int(os.environ.get("OMP_NUM_THREADS", CPU_THREADS))
+    out = None
+    try:
+        from scipy.linalg import lapack
+        af = np.asfortranarray(a)
+        lapack.sgeqrf(np.asfortranarray(a[:4096]))
+        t = time.time(); qr_, tau, _, info = lapack.sgeqrf(af); t_geqrf = time.time() - t
+        t = time.time(); qq, _, info = lapack.sorgqr(qr_[:, :n], tau); t_orgqr = time.time() - t
+        out = {"value": f_qr(sample_rows, n) / (t_geqrf + t_orgqr) / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "lapack",
+               "sample": "scipy.linalg.lapack (OpenBLAS) sgeqrf + sorgqr on %d x %d U(-1,1), %.2f s on %d threads; F_QR = 4MN^2 - 4/3 N^3" % (
+                   sample_rows, n, t_geqrf + t_orgqr, cores),
+               "sgeqrf_only_gflops": f_r(sample_rows, n) / t_geqrf / 1e9, "orth_fro": ro.orthogonality_fro(qq)}
+    except Exception as e:  # no LAPACK on the box: the oracle port becomes the baseline
+        out = None
+        lapack_error = str(e)
     md = ro.FP32_NOTC if mode_name == "fp32_notc" else ro.FP32_TC_COR   # the oracle models the two north-star modes
     ro.qr(a[:4096], md, False)
     t = time.time()
     st, q, r = ro.qr(a, md, False)
     dt = time.time() - t
-    cores = int(os.environ.get("OMP_NUM_THREADS", CPU_THREADS))
-    out = {"value": f_qr(sample_rows, n) / dt / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
-           "sample": "oracle/ref_tsqr.c (%s, reference algorithm, OpenMP) on %d x %d U(-1,1), %.2f s; F_QR = 4MN^2 - 4/3 N^3" % (
-               mode_name, sample_rows, n, dt),
-           "orth_fro": ro.orthogonality_fro(q), "residual": ro.residual(a, q, r)}
-    try:
-        from scipy.linalg import lapack
-        af = np.asfortranarray(a)
-        t = time.time(); qr_, tau, _, info = lapack.sgeqrf(af); t_geqrf = time.time() - t
-        t = time.time(); qq, _, info = lapack.sorgqr(qr_[:, :n], tau); t_orgqr = time.time() - t
-        out["lapack"] = {"sgeqrf_gflops": f_r(sample_rows, n) / t_geqrf / 1e9,
-                         "sgeqrf_sorgqr_gflops": f_qr(sample_rows, n) / (t_geqrf + t_orgqr) / 1e9,
-                         "library": "scipy.linalg.lapack (OpenBLAS)", "cores": cores,
-                         "orth_fro": ro.orthogonality_fro(qq)}
-    except Exception as e:  # LAPACK is a reported extra, never a requirement
-        out["lapack"] = {"error": str(e)}
+    port = {"value": f_qr(sample_rows, n) / dt / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ref_tsqr.c (%s, reference algorithm, OpenMP) on %d x %d U(-1,1), %.2f s" % (mode_name, sample_rows, n, dt),
+            "orth_fro": ro.orthogonality_fro(q), "residual": ro.residual(a, q, r)}
+    if out is None:
+        port["lapack_error"] = lapack_error
+        return port
+    out["oracle_port"] = port
     return out
 
 
 def pmc_traffic(kernel_class, m, n, mode):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc_hbm_traffic.json:
-    FETCH_SIZE x2 for gfx950, WRITE_SIZE exact -- separate --pmc passes).  Only valid for the workload
-    those passes were taken on (2^20 x 64, fp32_tc_cor); otherwise null."""
+    """HBM bytes per launch of the dominant kernel.  NOT measured in this run: replayed from the newest committed rocprofv3 PMC
+    summary (profiles/rNN_pmc_hbm_traffic.json: FETCH_SIZE x2 for gfx950, WRITE_SIZE exact, separate --pmc passes), valid only
+    for the workload those passes were taken on (2^20 x 64, fp32_tc_cor).  Returns (bytes or None, source label)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not files or m != 1 << 20 or n != 64 or mode != "fp32_tc_cor":
-        return None
+        return None, None
     try:
         data = json.load(open(files[-1]))
         for k in data["kernels"].values():
             if k.get("class") == kernel_class:
-                return k["hbm_bytes"]
+                return k["hbm_bytes"], "static: %s (rocprofv3 --pmc passes of an earlier run, not this one)" % os.path.relpath(files[-1], ROOT)
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -136,6 +143,9 @@ def main():
     ap.add_argument("--apply-waves", type=int, default=0)
     ap.add_argument("--policy", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true", help="use the row-partitioned driver even on one GPU")
+    ap.add_argument("--dist-comm", default="auto", choices=["auto", "rccl", "callbacks"],
+                    help="transport of the row-partitioned driver's two exchanges: raw RCCL communicator (C calls ncclAllReduce itself, "
+                         "no Python between kernels) or torch.distributed callbacks; auto = rccl when every rank can create it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo only to rehearse the multi-rank logic with several ranks on ONE GPU")
     ap.add_argument("--ld-pad", type=int, default=0, help="leading dimension = m + pad (experiments on DRAM channel mapping)")
@@ -187,11 +197,11 @@ def main():
             assert st == 0, st
     else:
         from tsqr_gpu_amd import dist as tdist
-        eng = tdist.HipEngine(mode, m, n, world)
+        eng = tdist.RowPartitionedQR(mode, m, n, comm=args.dist_comm)    # one C call per step; RCCL called from C on this stream
 
         def step():
-            st = tdist.qr_dist(d_q, ld, d_r, d_a, ld, m, n, eng, reorthogonalize=bool(args.reorth))
-            assert st == 0, st                              # (qr_dist is blocking like the single-GPU call: complete on return)
+            st = eng.qr(d_q, ld, d_r, d_a, ld, reorthogonalize=bool(args.reorth))
+            assert st == 0, st                              # (blocking like the single-GPU call: complete on return)
 
     def barrier():
         if world > 1:
@@ -250,12 +260,17 @@ def main():
             ach, peak, unit = alg_bytes / per_launch_s / 1e9, PEAK_HBM_TBS * 1e3, "GB/s"
         else:
             ach, peak, unit = alg_flops / per_launch_s / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
+        traffic, traffic_source = pmc_traffic(dom, m, n, args.mode)
+        engine_name = bq.ENGINE_NAMES.get(eng.last_engine if eng is not None else bq.last_engine(), "?")
         roofline = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                    "frac": ach / peak, "traffic": pmc_traffic(dom, m, n, args.mode),
+                    "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
+                    "note": "HBM fractions are fabric-side: the same A is factored every step (the reference's own protocol, "
+                            "src/test.cu:299-309) and stays largely resident in the 256 MiB Infinity Cache between the two passes "
+                            "and between steps; FETCH_SIZE counts those hits as memory-side requests",
                     "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
                     "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
-                    "r_factor_engine": bq.ENGINE_NAMES.get(eng.last_engine if eng is not None else bq.last_engine(), "?"),
+                    "r_factor_engine": engine_name,
                     "whole_path": {"tflops": gflops / 1e3 / world, "peak_tflops_f32_matrix": PEAK_F32_MATRIX_TFLOPS,
                                    "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
                                    "algorithmic_gbs": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e9,
@@ -264,10 +279,11 @@ def main():
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
-               "config": {"workload": "M=2^%d x N=%d per GPU, %s, reorth=%d, U(-1,1); global %d x %d; F_QR=4MN^2-4/3N^3" % (
-                   int(np.log2(m)) if m & (m - 1) == 0 else -1, n, args.mode, args.reorth, m_glob, n),
-                   "m_per_gpu": m, "n": n, "mode": args.mode, "reorthogonalize": bool(args.reorth),
-                   "parallelism": "row-partitioned x%d" % world},
+               "config": {"workload": "M=2^%d x N=%d per GPU, %s, reorth=%d, U(-1,1); global %d x %d; F_QR=4MN^2-4/3N^3; R-factor engine: %s" % (
+                   int(np.log2(m)) if m & (m - 1) == 0 else -1, n, args.mode, args.reorth, m_glob, n, engine_name),
+                   "engine": engine_name, "m_per_gpu": m, "n": n, "mode": args.mode, "reorthogonalize": bool(args.reorth),
+                   "parallelism": "row-partitioned x%d" % world,
+                   "dist_transport": (eng.transport if eng is not None else None)},
                "orth_fro": orth_fro, "orth_ref_metric": orth_fro / np.sqrt(n), "residual": residual,
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:

@@ -11,6 +11,11 @@
  * buffer are DEVICE pointers owned by the caller (h_wl is pinned host memory); the call is
  * blocking -- it returns after the stream is idle (reference src/blockqr.cu:140); nothing
  * is allocated inside; `a` may be overwritten (it is for n > 64).
+ * Re-entrant like the reference's entry point (src/blockqr.cu:394-433): a call keeps no state outside its arguments, so several
+ * host threads may factor different matrices at the same time, each with its own buffers and stream (settings made with the
+ * tsqr_mi_set_* calls are process-wide; tsqr_mi_last_error / tsqr_mi_last_engine / the event profile are per host thread).
+ * h_wl: when it is pinned host memory of at least 8 words the engine writes its status words and completion flag there; a smaller
+ * or pageable h_wl (e.g. sized with the reference's batch_size + 1 rule for m <= 128) is left untouched.
  */
 #ifndef TSQR_MI_H
 #define TSQR_MI_H
@@ -98,13 +103,31 @@ int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t l
 /* r (n x n) <- r2 * r (upper triangular product, used after a reorthogonalisation sweep) */
 int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t n, void* wq, void* stream);
 
-/* Row-partitioned TSQR over an RCCL communicator (ncclComm_t passed as void*).  Every rank passes its
- * own row block; r is identical on all ranks on return.  n <= 64. */
+/* Row-partitioned TSQR (the reference has no multi-GPU path): one call per rank, every rank passes its own
+ * row block (m_local may differ between ranks), r is bitwise identical on all ranks on return, n <= 64.  It is the SAME ladder as
+ * tsqr_mi_qr_f32 with two exchange hooks switched on, all enqueued on `stream` with no host wait before the end of the call:
+ *   Gram levels:        all-reduce (sum) of the Gram tiles + the local row count: <= 2561 doubles.  Every rank then factors the
+ *                       same matrix with thresholds from the same (global) row count, so the accept / reject decisions agree on
+ *                       all ranks by construction -- a NaN anywhere reaches everyone through the sum;
+ *   Householder engine: all-gather of the n x n local R factors, every rank folds the same (nranks n) x n stack.
+ * Work buffers: tsqr_mi_working_{q,r}_size_dist(m_local, n, nranks) elements; gather_buf: nranks*n*n floats.
+ * tsqr_mi_qr_f32_dist: RCCL on the caller's ncclComm_t (passed as void*; librccl is resolved with dlopen, preferring the copy the
+ * process has already loaded).  tsqr_mi_qr_f32_dist_cb: caller-supplied collectives (blocking or stream-ordered; in place sum /
+ * gather in rank order), e.g. torch.distributed over gloo -- what the two-process tests use. */
+size_t tsqr_mi_working_q_size_dist(size_t m_local, size_t n, int nranks);
+size_t tsqr_mi_working_r_size_dist(size_t m_local, size_t n, int nranks);
 int tsqr_mi_qr_f32_dist(int mode, int reorth,
                         float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                         size_t m_local, size_t n,
                         void* wq, void* wr, float* gather_buf /* nranks*n*n floats */,
                         void* nccl_comm, int nranks, void* stream);
+typedef int (*tsqr_mi_allreduce_f64_cb)(void* user, double* buf /* device */, size_t count, void* stream);
+typedef int (*tsqr_mi_allgather_f32_cb)(void* user, const float* send /* device */, float* recv /* device, nranks*count */, size_t count, void* stream);
+int tsqr_mi_qr_f32_dist_cb(int mode, int reorth,
+                           float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                           size_t m_local, size_t n,
+                           void* wq, void* wr, float* gather_buf,
+                           tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream);
 
 /* Harness support (reference src/validation.cu:43-127, src/test.cu:147-165): accuracy metrics evaluated on the device in fp64.
  * scratch: n*n + 8 doubles of device memory.  out_host[0..4] = ||Q^T Q - I||_F^2, its diagonal part, its off-diagonal part,

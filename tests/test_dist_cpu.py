@@ -1,8 +1,14 @@
-"""world_size-2 gloo test of the row-partitioned TSQR driver (tsqr_gpu_amd/dist.py) on CPU.
+"""world_size-2 gloo tests of the row-partitioned TSQR driver (tsqr_gpu_amd/dist.py) on CPU.
 
-The product engine is the HIP library (no CPU fallback); here the exchange logic -- row partitioning, all_gather of the
-R factors, stacking order, R identical on all ranks, reorthogonalisation sweep -- is exercised with a numpy test double
-standing in for the two local kernels."""
+The product executes a rank's factorisation as ONE call into the HIP library (no CPU fallback, tsqr_mi_qr_f32_dist[_cb]); what can
+run without a GPU is everything around that call: RowPartitionedQR, the TorchCollectives transport (real gloo collectives between two
+processes) and the exchange PROTOCOL of the C ladder, restated here by a numpy double that keeps its rules:
+  * Gram engine: the all-reduced payload is [Gram entries ..., local row count]; thresholds come from the summed row count, so
+    ranks with DIFFERENT block heights take the same accept / reject decision;
+  * a rejected Gram level escalates on every rank alike (the verdict is a function of the all-reduced payload only);
+  * Householder engine: all-gather of the n x n local R factors in rank order, every rank folds the same stack -> identical R;
+  * Reorthogonalize = true: second sweep on Q, R <- R2 * R1.
+The same collectives + the real engine are covered on the GPU box by tests/test_gpu_dist.py (two processes, one GPU, gloo)."""
 import os
 import socket
 
@@ -12,99 +18,107 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-class NumpyEngine:
-    """Test double for dist.HipEngine: same interface, LAPACK arithmetic."""
+class NumpyRowBackend:
+    """Test double for dist.HipBackend: same qr_dist signature, LAPACK arithmetic, the C ladder's exchange protocol."""
 
-    def __init__(self, n, use_gram=False, reject_levels=()):
-        self.n = n
-        self.use_gram = use_gram
-        self.reject_levels = reject_levels          # Gram levels this double pretends to reject (exercises the escalation)
+    def __init__(self, n, coll, engine="gram", reject_levels=()):
+        self.n, self.coll = n, coll
+        self.engine = engine                        # "gram" (auto ladder) or "householder" (policy 1)
+        self.reject_levels = set(reject_levels)     # Gram levels this double pretends to reject (exercises the escalation)
         self.last_engine = 0
-        self._z = None
-
-    def gram(self, level, a, lda, m):
-        am = self._cm(a, lda, m, self.n).astype(np.float64)
-        return torch.from_numpy((am.T @ am).reshape(-1).copy())
-
-    def chol(self, level, g, m, r):
-        if level in self.reject_levels:
-            return 1
-        if level == 1 and "1-once" in self.reject_levels and not getattr(self, "_l1_rejected", False):
-            self._l1_rejected = True                # the fp64 level fails on A but works on Q1 (the shifted-Cholesky situation)
-            return 1
-        gm = g.numpy().reshape(self.n, self.n)
-        rr = np.linalg.cholesky(gm).T
-        r.copy_(torch.from_numpy(np.ascontiguousarray(rr.T.astype(np.float32))))
-        self._z = np.linalg.inv(rr)
-        return 0
-
-    def chol_shifted(self, g, m, r):
-        if "s" in self.reject_levels:               # pretend even the shifted factorisation fails (non-finite data on the GPU)
-            return 1
-        gm = g.numpy().reshape(self.n, self.n)
-        rr = np.linalg.cholesky(gm + 1e-7 * np.trace(gm) * np.eye(self.n)).T
-        r.copy_(torch.from_numpy(np.ascontiguousarray(rr.T.astype(np.float32))))
-        self._z = np.linalg.inv(rr)
-        self.shifted_calls = getattr(self, "shifted_calls", 0) + 1
-        return 0
-
-    def chol_async(self, level, g, m, r):
-        self._pending = self.chol(level, g, m, r)
-        if self._pending:                           # a rejected level still leaves *some* Z behind on the GPU; mimic that
-            self._z = np.eye(self.n)
-
-    def chol_status(self, m):
-        return self._pending
-
-    def apply_z(self, q, ldq, a, lda, m):
-        am = self._cm(a, lda, m, self.n).astype(np.float64)
-        self._cm(q, ldq, m, self.n)[:] = (am @ self._z).astype(np.float32)
+        self.rows_seen = []                         # global row counts read from the all-reduced payloads
 
     @staticmethod
     def _cm(t, ld, m, n):          # column-major m x n view of a tensor
         return t.numpy().reshape(-1)[: ld * n].reshape(n, ld)[:, :m].T
 
-    def local_r(self, a, lda, m, r):
-        am = self._cm(a, lda, m, self.n).astype(np.float64)
+    def _gram_level(self, am, level):
+        n = self.n
+        payload = torch.zeros(n * n + 1, dtype=torch.float64)
+        payload[: n * n] = torch.from_numpy((am.T @ am).reshape(-1).copy())
+        payload[n * n] = float(am.shape[0])                         # the row count travels with the tiles
+        self.coll.allreduce_f64(payload)
+        g = payload[: n * n].numpy().reshape(n, n)
+        rows = float(payload[n * n])
+        self.rows_seen.append(rows)
+        if level in self.reject_levels:
+            return None
+        limit = min(128.0, max(4.0, 0.12 * np.sqrt(rows)))          # the bf16 level's S bound: a function of the GLOBAL row count
+        try:
+            r = np.linalg.cholesky(g).T
+        except np.linalg.LinAlgError:
+            return None
+        z = np.linalg.inv(r)
+        s = float(np.sum((np.sqrt(np.diag(g))[:, None] * z) ** 2) / n)
+        if level == 2 and s > limit:
+            return None
+        return r
+
+    def _householder(self, am):
+        n = self.n
+        rl = np.zeros((n, n))
         rr = np.linalg.qr(am, mode="r")
-        full = np.zeros((self.n, self.n))
-        full[: rr.shape[0], :] = rr
-        r.copy_(torch.from_numpy(np.ascontiguousarray(full.T.astype(np.float32))))
+        rl[: rr.shape[0], :] = rr
+        send = torch.from_numpy(np.ascontiguousarray(rl.T.astype(np.float32)).reshape(-1))     # column-major n x n
+        recv = torch.zeros(self.coll.world * n * n, dtype=torch.float32)
+        self.coll.allgather_f32(send, recv)
+        stack = np.concatenate([recv[k * n * n:(k + 1) * n * n].numpy().reshape(n, n).T for k in range(self.coll.world)], axis=0)
+        return np.linalg.qr(stack.astype(np.float64), mode="r")
 
-    def apply_rinv(self, q, ldq, a, lda, m, r):
-        am = self._cm(a, lda, m, self.n).astype(np.float64)
-        rm = r.numpy().T.astype(np.float64)
-        qm = np.linalg.solve(rm.T, am.T).T
-        self._cm(q, ldq, m, self.n)[:] = qm.astype(np.float32)
+    def _sweep(self, am):
+        if self.engine == "gram":
+            for level in (2, 1):
+                r = self._gram_level(am, level)
+                if r is not None:
+                    self.last_engine = max(self.last_engine, 3 if level == 2 else 1)
+                    return r
+            self.last_engine = 2
+        return self._householder(am)
 
-    def rmul(self, r, r2):
-        r.copy_(torch.from_numpy(np.ascontiguousarray((r2.numpy().T.astype(np.float64) @ r.numpy().T.astype(np.float64)).T.astype(np.float32))))
+    def qr_dist(self, q, ldq, r, ldr, a, lda, m_local, reorth):
+        am = self._cm(a, lda, m_local, self.n).astype(np.float64)
+        r1 = self._sweep(am)
+        d = np.sign(np.diag(r1)); d[d == 0] = 1.0
+        r1 = d[:, None] * r1
+        qm = np.linalg.solve(r1.T, am.T).T
+        if reorth:
+            r2 = self._sweep(qm)
+            d = np.sign(np.diag(r2)); d[d == 0] = 1.0
+            r2 = d[:, None] * r2
+            qm = np.linalg.solve(r2.T, qm.T).T
+            r1 = r2 @ r1
+        self._cm(q, ldq, m_local, self.n)[:] = qm.astype(np.float32)
+        r.copy_(torch.from_numpy(np.ascontiguousarray(np.triu(r1).T.astype(np.float32))))
+        return 0
 
-    def empty(self, *shape):
-        return torch.empty(*shape, dtype=torch.float32)
 
-
-def _worker(rank, world, port, m_local, n, reorth, out, use_gram=False, reject=()):
+def _worker(rank, world, port, heights, n, reorth, out, engine, reject):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tsqr_gpu_amd import dist as tdist
     rng = np.random.Generator(np.random.MT19937(123))
-    a_glob = rng.uniform(-1, 1, size=(world * m_local, n)).astype(np.float32)
-    a_loc = a_glob[rank * m_local:(rank + 1) * m_local]
+    m_glob = sum(heights)
+    a_glob = rng.uniform(-1, 1, size=(m_glob, n)).astype(np.float32)
+    row0 = sum(heights[:rank]); m_local = heights[rank]
+    a_loc = a_glob[row0:row0 + m_local]
     a = torch.from_numpy(np.ascontiguousarray(a_loc.T))
     q = torch.zeros(n, m_local)
     r = torch.zeros(n, n)
-    eng = NumpyEngine(n, use_gram, reject)
-    st = tdist.qr_dist(q, m_local, r, a, m_local, m_local, n, eng, reorthogonalize=reorth)
+    backend = NumpyRowBackend(n, tdist.TorchCollectives(), engine, reject)
+    drv = tdist.RowPartitionedQR(3, m_local, n, backend=backend)
+    st = drv.qr(q, m_local, r, a, m_local, reorthogonalize=reorth)
     rs = [torch.zeros(n, n) for _ in range(world)]
     dist.all_gather(rs, r)
-    qs = [torch.zeros(n, m_local) for _ in range(world)]
-    dist.all_gather(qs, q)
+    mmax = max(heights)
+    qpad = torch.zeros(n, mmax); qpad[:, :m_local] = q
+    qs = [torch.zeros(n, mmax) for _ in range(world)]
+    dist.all_gather(qs, qpad)
     if rank == 0:
-        qg = np.concatenate([t.numpy().T for t in qs], axis=0).astype(np.float64)
+        qg = np.concatenate([t.numpy().T[:heights[k]] for k, t in enumerate(qs)], axis=0).astype(np.float64)
         rg = r.numpy().T.astype(np.float64)
-        out.put({"engine": eng.last_engine, "st": st, "r_same": all(torch.equal(rs[0], t) for t in rs),
+        out.put({"engine": drv.last_engine, "st": st, "r_same": all(torch.equal(rs[0], t) for t in rs), "world": drv.world,
+                 "rows_seen": backend.rows_seen,
                  "res": float(np.linalg.norm(qg @ rg - a_glob) / np.linalg.norm(a_glob)),
                  "orth": float(np.linalg.norm(qg.T @ qg - np.eye(n))),
                  "lower": float(np.abs(np.tril(rg, -1)).max())})
@@ -116,11 +130,11 @@ def _free_port():
     return p
 
 
-def _run(m_local, n, reorth, use_gram=False, reject=()):
+def _run(heights, n, reorth, engine="gram", reject=()):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, m_local, n, reorth, out, use_gram, reject)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, heights, n, reorth, out, engine, reject)) for r in range(2)]
     for p in procs:
         p.start()
     res = out.get(timeout=120)
@@ -130,27 +144,29 @@ def _run(m_local, n, reorth, use_gram=False, reject=()):
     return res
 
 
-def test_two_rank_row_partitioned_tsqr():
-    res = _run(500, 24, False)
-    assert res["st"] == 0 and res["r_same"]
+def test_two_rank_householder_all_gather():
+    res = _run((500, 500), 24, False, engine="householder")
+    assert res["st"] == 0 and res["r_same"] and res["world"] == 2
     assert res["res"] < 1e-6 and res["orth"] < 1e-5 and res["lower"] == 0.0
 
 
 def test_two_rank_reorth_and_short_blocks():
-    res = _run(40, 64, True)      # each rank's block has fewer rows than columns: only the global matrix is tall
+    res = _run((40, 40), 64, True, engine="householder")      # each block has fewer rows than columns: only the global matrix is tall
     assert res["st"] == 0 and res["r_same"]
     assert res["res"] < 1e-6 and res["orth"] < 1e-5
 
 
-def test_two_rank_gram_engine_and_escalation():
-    res = _run(600, 32, False, use_gram=True)                       # Gram level 2 accepted: all-reduce of G
+def test_two_rank_gram_engine_unequal_blocks_share_the_row_count():
+    """ranks with different block heights: the verdict thresholds must come from the all-reduced row count, not from m_local"""
+    res = _run((700, 300), 32, False)
     assert res["st"] == 0 and res["r_same"] and res["engine"] == 3
+    assert res["rows_seen"] == [1000.0]                       # one exchange, global rows in the payload
     assert res["res"] < 1e-6 and res["orth"] < 1e-5 and res["lower"] == 0.0
-    res = _run(600, 32, True, use_gram=True, reject=(2,))           # level 2 rejected on every rank -> fp64 level
+
+
+def test_two_rank_escalation_is_identical_on_all_ranks():
+    res = _run((600, 600), 32, True, reject=(2,))             # level 2 rejected on every rank -> fp64 level, both sweeps
     assert res["st"] == 0 and res["r_same"] and res["engine"] == 1 and res["orth"] < 1e-5
-    res = _run(600, 32, False, use_gram=True, reject=(2, 1, "s"))   # nothing Gram-based works -> Householder all-gather path
+    assert res["rows_seen"] == [1200.0] * 4
+    res = _run((600, 500), 32, False, reject=(2, 1))          # nothing Gram-based works -> Householder all-gather path
     assert res["st"] == 0 and res["r_same"] and res["engine"] == 2 and res["orth"] < 1e-5 and res["res"] < 1e-6
-    res = _run(600, 32, False, use_gram=True, reject=(2, 1))        # both rejected, also on Q1 -> two shifted steps
-    assert res["st"] == 0 and res["r_same"] and res["engine"] == 4 and res["orth"] < 1e-4 and res["res"] < 1e-6
-    res = _run(600, 32, False, use_gram=True, reject=(2, "1-once")) # both rejected on A, fp64 level fine on Q1 -> shifted Cholesky QR
-    assert res["st"] == 0 and res["r_same"] and res["engine"] == 4 and res["orth"] < 1e-5 and res["res"] < 1e-6 and res["lower"] == 0.0

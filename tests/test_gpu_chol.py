@@ -1,6 +1,7 @@
-"""GPU tests of the pipelined Cholesky / inverse kernel (tsqr_gpu_amd/csrc/chol_wg.hip), the n x n step between the Gram pass and
-the apply pass -- the role of the reference's root tile QR (src/tsqr.cu:1164-1172).  Checked against numpy fp64 Cholesky and
-inverse for both accumulator layouts the Gram kernels produce, ragged n, the shifted variant and the reject paths."""
+"""GPU tests of chol_kernel (tsqr_gpu_amd/csrc/tsqr_kernels.hip), the n x n step between the Gram pass and the apply pass:
+R = chol(G), Z = inverse(R), accept / reject verdict -- the role of the reference's root tile QR (src/tsqr.cu:1164-1172).
+Checked against numpy fp64 Cholesky and inverse for both accumulator layouts the Gram kernels produce, ragged n, the shifted
+variant and the reject paths."""
 import ctypes
 import os
 
@@ -17,9 +18,9 @@ def st():
     assert torch.cuda.is_available()
     so = os.path.join(ROOT, "tsqr_gpu_amd", "csrc", "libtsqr_selftest.so")
     L = ctypes.CDLL(so)
-    L.tsqr_selftest_chol_mfma.restype = ctypes.c_float
-    L.tsqr_selftest_chol_mfma.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + \
-        [ctypes.c_int] * 4 + [ctypes.c_double, ctypes.c_double, ctypes.c_int]
+    L.tsqr_selftest_chol.restype = ctypes.c_float
+    L.tsqr_selftest_chol.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + \
+        [ctypes.c_int] * 3 + [ctypes.c_double, ctypes.c_int]
     return L, torch
 
 
@@ -39,7 +40,9 @@ def pack_tiles(g, n, f32_layout):
     return np.concatenate(out)
 
 
-def run(st, g, n, f32_layout, level=1, rows=1 << 20, shift=0.0, ldr=None, reps=0):
+def run(st, g, n, level=1, rows=1 << 20, ldr=None, reps=0):
+    """level 2 packs the tiles in the f32 accumulator layout, levels 1 / 3 in the f64 layout (what each Gram kernel writes)"""
+    f32_layout = 1 if level == 2 else 0
     L, torch = st
     nt = (n + 15) // 16
     NP = 16 * nt
@@ -48,8 +51,7 @@ def run(st, g, n, f32_layout, level=1, rows=1 << 20, shift=0.0, ldr=None, reps=0
     r = torch.full((n * ldr,), float("nan"), device="cuda")
     z = torch.full((NP * NP,), float("nan"), device="cuda")
     status = torch.zeros(4, dtype=torch.int32, device="cuda")
-    ms = L.tsqr_selftest_chol_mfma(r.data_ptr(), ldr, z.data_ptr(), status.data_ptr(), gs.data_ptr(), n, nt, int(f32_layout), level,
-                                   float(rows), float(shift), reps)
+    ms = L.tsqr_selftest_chol(r.data_ptr(), ldr, z.data_ptr(), status.data_ptr(), gs.data_ptr(), n, nt, level, float(rows), reps)
     torch.cuda.synchronize()
     assert ms >= 0
     R = r.cpu().numpy().reshape(n, ldr)[:, :n].T.astype(np.float64)      # column-major -> R[row, col]
@@ -70,10 +72,10 @@ def spd(n, cond, seed):
 
 
 @pytest.mark.parametrize("n", [64, 51, 48, 33, 17, 16, 5, 1])
-@pytest.mark.parametrize("f32_layout", [0, 1])
-def test_matches_numpy_cholesky(st, n, f32_layout):
-    g, _ = spd(n, 30.0, n)
-    R, Z, status, ratio, scond, _ = run(st, g, n, f32_layout, level=1, ldr=n + 3)
+@pytest.mark.parametrize("level", [1, 2])
+def test_matches_numpy_cholesky(st, n, level):
+    g, _ = spd(n, 3.0 if level == 2 else 30.0, n)
+    R, Z, status, ratio, scond, _ = run(st, g, n, level=level, ldr=n + 3)
     ref = np.linalg.cholesky(g).T
     assert status == 0
     assert np.all(np.tril(R, -1) == 0.0)                                  # exact zeros below the diagonal
@@ -98,7 +100,7 @@ def test_diag_tiles_use_upper_triangle(st):
     il = np.tril_indices(n, -1)
     g_bad[il] *= 1.0 + 1e-3                                               # spoil the strict lower triangle
     # pack_tiles reads diagonal tiles from g_bad (both triangles), off-diagonal tiles from its upper part only
-    R, _, status, _, _, _ = run(st, g_bad, n, 1, level=1)
+    R, _, status, _, _, _ = run(st, g_bad, n, level=2)
     assert status == 0
     ref = np.linalg.cholesky(g).T
     assert np.abs(R - ref).max() <= 2e-7 * np.abs(ref).max()
@@ -107,25 +109,25 @@ def test_diag_tiles_use_upper_triangle(st):
 def test_verdicts(st):
     n = 64
     g, _ = spd(n, 3.0, 1)
-    assert run(st, g, n, 1, level=2)[2] == 0                              # well conditioned: the bf16 level accepts
+    assert run(st, g, n, level=2)[2] == 0                                 # well conditioned: the bf16 level accepts
     g2, _ = spd(n, 1e4, 2)
-    assert run(st, g2, n, 1, level=2)[2] == 1                             # cond 1e4: S far beyond the bound of the bf16 level
-    assert run(st, g2, n, 0, level=1)[2] == 0                             # the fp64 level takes it
+    assert run(st, g2, n, level=2)[2] == 1                                # cond 1e4: S far beyond the bound of the bf16 level
+    assert run(st, g2, n, level=1)[2] == 0                                # the fp64 level takes it
     g3 = g.copy(); g3[:, 7] = g3[:, 6]; g3[7, :] = g3[6, :]               # exactly dependent columns -> zero pivot
-    assert run(st, g3, n, 0, level=1)[2] == 1
-    R, Z, status, _, _, _ = run(st, g3, n, 0, level=3, shift=11 * 2.0 ** -53)
+    assert run(st, g3, n, level=1)[2] == 1
+    R, Z, status, _, _, _ = run(st, g3, n, level=3)
     assert status == 0 and np.all(np.isfinite(R)) and np.all(np.isfinite(Z))
     g4 = g.copy(); g4[3, 3] = np.nan
-    assert run(st, g4, n, 0, level=1)[2] == 1 and run(st, g4, n, 0, level=3, shift=1e-15)[2] == 1
+    assert run(st, g4, n, level=1)[2] == 1 and run(st, g4, n, level=3)[2] == 1
     g5 = g * 1e-60                                                        # column norms in the fp32 denormal product range
-    assert run(st, g5, n, 1, level=2, rows=1 << 20)[2] == 1 and run(st, g5, n, 0, level=1)[2] == 0
+    assert run(st, g5, n, level=2, rows=1 << 20)[2] == 1 and run(st, g5, n, level=1)[2] == 0
 
 
 def test_shift_value(st):
     n, rows = 48, 1 << 18
     g, _ = spd(n, 5.0, 9)
     coef = 11 * 2.0 ** -53
-    R, _, status, _, _, _ = run(st, g, n, 0, level=3, rows=rows, shift=coef)
+    R, _, status, _, _, _ = run(st, g, n, level=3, rows=rows)
     s = coef * (rows * n + n * (n + 1)) * np.trace(g)
     ref = np.linalg.cholesky(g + s * np.eye(n)).T
     assert status == 0 and np.abs(R - ref).max() <= 2e-7 * np.abs(ref).max()
@@ -134,6 +136,6 @@ def test_shift_value(st):
 def test_timing_report(st):
     g, _ = spd(64, 3.0, 1)
     for n in (16, 32, 48, 64):
-        ms = run(st, g[:n, :n], n, 1, level=2, reps=50)[5]
-        print("chol_wg_kernel n=%d: %.2f us per launch (back to back)" % (n, ms * 1e3))
+        ms = run(st, g[:n, :n], n, level=2, reps=50)[5]
+        print("chol_kernel n=%d: %.2f us per launch (back to back)" % (n, ms * 1e3))
     assert ms < 0.05

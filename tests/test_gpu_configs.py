@@ -63,8 +63,8 @@ def test_c4_2pow23_x_64_row_partitioned_driver_one_rank(env):
     g = torch.Generator(device="cuda"); g.manual_seed(4)
     d_a = torch.rand(n, m, generator=g, device="cuda", dtype=torch.float32) * 2 - 1
     d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
-    eng = tdist.HipEngine(bq.compute_mode.fp32_tc_cor, m, n, 1)
-    assert tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng) == 0
+    eng = tdist.RowPartitionedQR(bq.compute_mode.fp32_tc_cor, m, n)
+    assert eng.qr(d_q, m, d_r, d_a, m) == 0
     torch.cuda.synchronize()
     assert eng.last_engine == 3
     assert harness.orthogonality_fro(d_q, m, n) < 1e-5
@@ -111,7 +111,8 @@ def test_cpp_dist_entry_point_over_rccl_single_rank(env, mode, policy, want, reo
         a = oracle.uniform_matrix(m, n, seed=17)
         d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
         d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
-        wq = torch.empty(bq.get_working_q_size(m, n), device="cuda"); wr = torch.empty(bq.get_working_r_size(m, n), device="cuda")
+        wq = torch.empty(bq.lib().tsqr_mi_working_q_size_dist(m, n, 1), device="cuda")
+        wr = torch.empty(bq.lib().tsqr_mi_working_r_size_dist(m, n, 1), device="cuda")
         gather = torch.empty(n * n, device="cuda")
         bq.set_policy(policy)
         try:
@@ -144,8 +145,8 @@ def test_row_partitioned_driver_ill_conditioned_shifted_path(env, mode):
     s = torch.logspace(0, -8, n, dtype=torch.float64)
     d_a = harness.latms(m, n, n, s, seed=9)
     d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
-    eng = tdist.HipEngine(bq.compute_mode[mode], m, n, 1)
-    assert tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=True) == 0
+    eng = tdist.RowPartitionedQR(bq.compute_mode[mode], m, n)
+    assert eng.qr(d_q, m, d_r, d_a, m, reorthogonalize=True) == 0
     torch.cuda.synchronize()
     assert eng.last_engine == 4
     assert harness.orthogonality_fro(d_q, m, n) < 1e-5 and harness.residual(d_q, d_r, d_a, m, n) < 2e-6
@@ -161,8 +162,8 @@ def test_row_partitioned_driver_exactly_dependent_columns(env):
     d_a = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
     d_a[0, :] = 1.0; d_a[n // 2, :] = -3.0
     d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
-    eng = tdist.HipEngine(bq.compute_mode.fp32_tc_cor, m, n, 1)
-    assert tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=True) == 0
+    eng = tdist.RowPartitionedQR(bq.compute_mode.fp32_tc_cor, m, n)
+    assert eng.qr(d_q, m, d_r, d_a, m, reorthogonalize=True) == 0
     torch.cuda.synchronize()
     assert eng.last_engine == 4
     assert harness.residual(d_q, d_r, d_a, m, n) < 2e-6 and harness.orthogonality_fro(d_q, m, n) < 1.01

@@ -1,0 +1,127 @@
+"""Two processes, ONE GPU, gloo: the row-partitioned driver with the PRODUCT engine (tsqr_mi_qr_f32_dist_cb: the C ladder calling
+back into torch.distributed for its two exchanges).  Checks the global factorisation against fp64 LAPACK and the reference
+restatement (oracle), unequal block heights, the Householder all-gather branch (policy 1, incl. blocks shorter than the panel),
+reorthogonalisation and the escalation of an ill-conditioned input -- i.e. that every rank takes the same branch and ends with
+the same R.  (RCCL itself refuses two ranks on one device; the raw-communicator transport is exercised on one rank in
+tests/test_gpu_configs.py and on the 8-GPU node by bench.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, heights, n, mode, reorth, policy, cond, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tsqr_gpu_amd import blockqr as bq, dist as tdist
+    rng = np.random.Generator(np.random.MT19937(7))
+    m_glob = sum(heights)
+    if cond > 1:
+        u, _ = np.linalg.qr(rng.standard_normal((m_glob, n)))
+        v, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        a_glob = ((u * np.geomspace(1.0, 1.0 / cond, n)) @ v.T).astype(np.float32)
+    else:
+        a_glob = rng.uniform(-1, 1, size=(m_glob, n)).astype(np.float32)
+    row0 = sum(heights[:rank]); m_local = heights[rank]
+    d_a = torch.from_numpy(np.ascontiguousarray(a_glob[row0:row0 + m_local].T)).cuda()
+    keep = d_a.clone()
+    d_q = torch.empty(n, m_local, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+    bq.set_policy(policy)
+    drv = tdist.RowPartitionedQR(bq.compute_mode[mode], m_local, n, comm="callbacks")
+    st = drv.qr(d_q, m_local, d_r, d_a, m_local, reorthogonalize=reorth)
+    torch.cuda.synchronize()
+    a_untouched = bool(torch.equal(keep, d_a))
+    r = d_r.cpu()
+    rs = [torch.zeros(n, n) for _ in range(world)]
+    dist.all_gather(rs, r)
+    mmax = max(heights)
+    qpad = torch.zeros(n, mmax); qpad[:, :m_local] = d_q.cpu()
+    qs = [torch.zeros(n, mmax) for _ in range(world)]
+    dist.all_gather(qs, qpad)
+    eng = torch.tensor([drv.last_engine]); engs = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(engs, eng)
+    if rank == 0:
+        qg = np.concatenate([t.numpy().T[:heights[k]] for k, t in enumerate(qs)], axis=0).astype(np.float64)
+        rg = r.numpy().T.astype(np.float64)
+        out.put({"st": st, "transport": drv.transport, "engines": [int(e.item()) for e in engs], "a_untouched": a_untouched,
+                 "r_same": all(torch.equal(rs[0], t) for t in rs), "q": qg, "r": rg, "a": a_glob})
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(heights, n, mode="fp32_tc_cor", reorth=False, policy=0, cond=1.0):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, heights, n, mode, reorth, policy, cond, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def _check(res, oracle, orth_tol=5e-6, r_tol=1e-5):
+    a, q, r = res["a"], res["q"], res["r"]
+    n = a.shape[1]
+    assert res["st"] == 0 and res["r_same"] and res["a_untouched"]
+    assert len(set(res["engines"])) == 1                       # every rank ended on the same engine
+    assert np.abs(np.tril(r, -1)).max() == 0.0
+    assert np.linalg.norm(q @ r - a) / np.linalg.norm(a) < 5e-7
+    assert np.linalg.norm(q.T @ q - np.eye(n)) < orth_tol
+    q2, r2 = np.linalg.qr(a.astype(np.float64))               # fp64 LAPACK, sign-normalised
+    _, rn = oracle.sign_normalise(q, r)
+    _, r2n = oracle.sign_normalise(q2, r2)
+    assert np.abs(rn - r2n).max() / np.abs(r2n).max() < r_tol
+
+
+@pytest.mark.parametrize("mode", ["fp32_tc_cor", "fp32_notc"])
+def test_two_ranks_gram_engine_unequal_blocks(oracle, mode):
+    res = _run((30000, 17777), 64, mode=mode)
+    assert res["transport"] == "torch.distributed callbacks" and res["engines"][0] == 3
+    _check(res, oracle)
+    # the reference restatement on the same global matrix (parity unpinned: bands, not bits)
+    _, qo, ro = oracle.qr(res["a"], oracle.FP32_TC_COR if mode == "fp32_tc_cor" else oracle.FP32_NOTC, False)
+    _, rn = oracle.sign_normalise(res["q"], res["r"])
+    _, ron = oracle.sign_normalise(qo, np.triu(ro))
+    assert np.abs(rn - ron).max() / np.abs(ron).max() < 2e-5
+
+
+@pytest.mark.parametrize("reorth", [False, True])
+def test_two_ranks_householder_all_gather(oracle, reorth):
+    """policy 1: local folds, all-gather of the two R factors, fold of the 128 x 64 stack on both ranks"""
+    res = _run((20000, 12345), 64, reorth=reorth, policy=1)
+    assert res["engines"][0] == 0
+    _check(res, oracle)
+
+
+def test_two_ranks_householder_blocks_shorter_than_the_panel(oracle):
+    """m_local < n on both ranks: the gathered stack and its fold scratch need the *_size_dist work buffers"""
+    res = _run((100, 60), 48, policy=1)
+    _check(res, oracle)
+
+
+def test_two_ranks_ill_conditioned_escalates_identically(oracle):
+    """cond 1e9 (1e7..1e8 after rounding to fp32): the bf16 and fp64 Gram levels reject on both ranks (same all-reduced matrix, same
+    thresholds), the shifted Cholesky QR two-step finishes the first sweep, the reorthogonalisation sweep brings Q back to O(eps)"""
+    res = _run((40000, 25000), 64, reorth=True, cond=1e9)
+    assert res["engines"][0] == 4
+    a, q, r = res["a"], res["q"], res["r"]
+    assert res["st"] == 0 and res["r_same"] and len(set(res["engines"])) == 1
+    assert np.abs(np.tril(r, -1)).max() == 0.0
+    assert np.linalg.norm(q @ r - a) / np.linalg.norm(a) < 2e-6
+    assert np.linalg.norm(q.T @ q - np.eye(64)) < 1e-5

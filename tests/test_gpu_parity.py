@@ -252,21 +252,24 @@ def test_auto_policy_escalation(bq, oracle, torch_cuda):
             assert oracle.orthogonality_fro(q) < 1e-5
 
 
-@pytest.mark.parametrize("mode,use_gram,want_engine", [("fp32_notc", None, 3), ("fp32_tc_cor", None, 3),
-                                                       ("fp32_notc", False, 0), ("fp32_tc_cor", False, 0)])
+@pytest.mark.parametrize("mode,policy,want_engine", [("fp32_notc", 0, 3), ("fp32_tc_cor", 0, 3),
+                                                     ("fp32_notc", 1, 0), ("fp32_tc_cor", 1, 0)])
 @pytest.mark.parametrize("reorth", [False, True])
-def test_dist_driver_single_rank(bq, oracle, torch_cuda, mode, use_gram, want_engine, reorth):
-    """The row-partitioned driver with its HIP engine on one rank (no collectives): staged C-ABI entry points
-    (Gram / Cholesky / apply by default -- bf16-split level for fp32_tc_cor, fp64 level for fp32_notc -- and
-    fold / apply when the Householder engine is forced)."""
+def test_dist_driver_single_rank(bq, oracle, torch_cuda, mode, policy, want_engine, reorth):
+    """The row-partitioned driver on one rank through its torch.distributed-callback transport (the collectives degenerate to
+    copies): Gram / Cholesky / apply by default, fold / all-gather / fold / apply when the Householder engine is forced."""
     torch = torch_cuda
     from tsqr_gpu_amd import dist as tdist
     m, n = 20000, 64
     a = oracle.uniform_matrix(m, n, seed=13)
     d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
     d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
-    eng = tdist.HipEngine(bq.compute_mode[mode], m, n, 1, use_gram=use_gram)
-    st = tdist.qr_dist(d_q, m, d_r, d_a, m, m, n, eng, reorthogonalize=reorth)
+    eng = tdist.RowPartitionedQR(bq.compute_mode[mode], m, n, comm="callbacks")
+    bq.set_policy(policy)
+    try:
+        st = eng.qr(d_q, m, d_r, d_a, m, reorthogonalize=reorth)
+    finally:
+        bq.set_policy(bq.POLICY_AUTO)
     torch.cuda.synchronize()
     assert st == 0 and eng.last_engine == want_engine
     q = d_q.cpu().numpy().T; r = d_r.cpu().numpy().T

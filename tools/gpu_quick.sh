@@ -1,5 +1,6 @@
 #!/bin/bash
-# quick GPU check: parity tests + headline bench line (+ optional extra command)
+# quick GPU check: parity tests + headline bench line; output also kept under gpurun_out/
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-python bench.py --steps 20 --no-cpu-baseline 2>/dev/null | python tools/bench_line.py "$1"
+mkdir -p gpurun_out
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/quick_pytest.log
+python bench.py --steps 20 --no-cpu-baseline 2>gpurun_out/quick_bench.err | python tools/bench_line.py "$1"

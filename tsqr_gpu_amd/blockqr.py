@@ -44,6 +44,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_qr_f32_dist", "tsqr_mi_set_tuning", "tsqr_mi_profile_enable", "tsqr_mi_profile_read",
     "tsqr_mi_set_policy", "tsqr_mi_last_engine", "tsqr_mi_set_tuning2",
     "tsqr_mi_gram_elems", "tsqr_mi_gram_f32", "tsqr_mi_chol_f32", "tsqr_mi_chol_status", "tsqr_mi_stream_wait", "tsqr_mi_apply_z_f32", "tsqr_mi_validate_f32",
+    "tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist", "tsqr_mi_qr_f32_dist_cb",
 ]
 
 _lib = None
@@ -94,6 +95,11 @@ def lib():
     L.tsqr_mi_rmul_f32.argtypes = [vp, sz, vp, sz, sz, vp, vp]
     L.tsqr_mi_qr_f32_dist.restype = ci
     L.tsqr_mi_qr_f32_dist.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, ci, vp]
+    L.tsqr_mi_qr_f32_dist_cb.restype = ci
+    L.tsqr_mi_qr_f32_dist_cb.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, ci, vp]
+    for name in ("tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist"):
+        getattr(L, name).restype = sz
+        getattr(L, name).argtypes = [sz, sz, ci]
     L.tsqr_mi_profile_enable.restype = None
     L.tsqr_mi_profile_enable.argtypes = [ci]
     L.tsqr_mi_profile_read.restype = ci

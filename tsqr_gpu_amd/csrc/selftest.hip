@@ -57,45 +57,27 @@ int tsqr_selftest_mfma_bf16(float* d, const float* a, const float* b) { hipLaunc
 int tsqr_selftest_split(float* out, const float* in, int n) { hipLaunchKernelGGL(split_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, out, in, n); return (int)hipDeviceSynchronize(); }
 }
 
-// ---- micro-benchmark of chol_kernel (ms per launch; gsum = summed Gram tiles in accumulator order) ----
-extern "C" float tsqr_selftest_chol_time(float* r, float* z, unsigned* status, const double* gsum, int n, int NT, int reps) {
-	hipEvent_t e0, e1;
-	hipEventCreate(&e0); hipEventCreate(&e1);
-	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY, nullptr, 0.0, nullptr, 0.0);
-	hipEventRecord(e0, 0);
-	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, r, (size_t)n, z, status, gsum, n, NT, 0, 9.094947017729282e-13f, INFINITY, nullptr, 0.0, nullptr, 0.0);
-	hipEventRecord(e1, 0);
-	hipEventSynchronize(e1);
-	float ms = 0.f;
-	hipEventElapsedTime(&ms, e0, e1);
-	return ms / reps;
-}
-
-// ---- the pipelined Cholesky / inverse kernel (chol_wg.hip): one launch (results) or `reps` launches (ms per launch) ----
-extern "C" float tsqr_selftest_chol_mfma(float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT, int f32_layout,
-                                         int level, double rows, double shift_per_row, int reps) {
+// ---- chol_kernel on summed Gram tiles (the step between the two streaming passes): one launch (results) + `reps` timed launches.
+// level 2: tiles in the f32 accumulator layout (bf16-split Gram pass), 1 / 3: f64 accumulator layout (fp64 Gram pass, 3 = shifted)
+extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT,
+                                    int level, double rows, int reps) {
 	tsqrmi::CholArgs a{};
 	a.r = r; a.ldr = ldr; a.z = z; a.status = status; a.host_status = nullptr; a.gsum = gsum; a.prev_status = nullptr; a.rows_dev = nullptr;
-	a.rows = rows; a.shift_coef = shift_per_row; a.n = n; a.NT = NT; a.f32_layout = f32_layout; a.level = level; a.scond_floor = 4.0f;
+	a.rows = rows; a.shift_coef = (level == 3) ? 11.0 * 1.1102230246251565e-16 : 0.0; a.n = n; a.NT = NT; a.level = level; a.scond_floor = 4.0f;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	hipLaunchKernelGGL(tsqrmi::chol_wg_kernel, dim3(1), dim3(256), 0, 0, a);
+	hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a);
 	hipEventRecord(e0, 0);
-	for (int i = 0; i < reps; i++) hipLaunchKernelGGL(tsqrmi::chol_wg_kernel, dim3(1), dim3(256), 0, 0, a);
+	for (int i = 0; i < reps; i++) hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0.f;
 	hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1);
 	if (hipGetLastError() != hipSuccess) return -1.0f;
 	return reps > 0 ? ms / reps : 0.0f;
 }
 
-#ifdef TSQR_CHOL_DBG
-extern "C" int tsqr_selftest_chol_stamps(long long* out) {
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tsqrmi::g_chol_stamps), sizeof(long long) * 4 * 16 * 8);
-}
-#endif
 
 // ---- copy kernel in the (c,q) chunk layout: the HBM ceiling of load_chunk + 16-B-per-lane stores ----
 template <int MODE>

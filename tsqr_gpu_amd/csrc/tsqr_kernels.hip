@@ -206,13 +206,10 @@ __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[1
 	}
 }
 
-#ifndef TSQR_FOLD_WAVES_PER_SIMD
-#define TSQR_FOLD_WAVES_PER_SIMD 2
-#endif
 // TRI: the folded blocks are 64-row upper-triangular R factors (tree levels with NT == 4): the wave's first block is copied
 // into R instead of folded and every panel skips the row tiles that are structurally zero.
 template <int NT, bool TRI = false>
-__global__ __launch_bounds__(256, TSQR_FOLD_WAVES_PER_SIMD) void fold_kernel(const FoldArgs a) {
+__global__ __launch_bounds__(256, 2) void fold_kernel(const FoldArgs a) {
 	constexpr int NP = 16 * NT;
 	constexpr int RP = (NP * (NP + 1)) / 2 + 16;         // packed upper triangle (+ slack for masked reads)
 	__shared__ float Rs[4][RP];
@@ -394,13 +391,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // Per-workgroup partial sums are written once and read once a few microseconds later.  Written with plain stores they displace
 // about as many bytes of A from the Infinity Cache, and the apply pass then runs 15 us slower at 2^20 x 64 (tools/mix_bench.py):
 // nontemporal on both sides keeps them out.
-#ifndef TSQR_PART_PLAIN
 __device__ __forceinline__ void part_store(double* p, double v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ double part_load(const double* p) { return __builtin_nontemporal_load(p); }
-#else
-__device__ __forceinline__ void part_store(double* p, double v) { *p = v; }
-__device__ __forceinline__ double part_load(const double* p) { return *p; }
-#endif
 
 struct GramArgs {
 	const float* a; size_t lda; size_t m; int n;
@@ -424,11 +416,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 	for (int t = 0; t < NTRI; t++) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
 	if (gw < a.nwaves) {
 		float p[NT][16];
-#ifndef TSQR_BLOCKED_CHUNKS
-		const int ch_end = a.nchunks, ch_step = a.nwaves, ch_begin = gw;
-#else
-		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw), ch_step = 1, ch_begin = gw * a.cpw;
-#endif
+		const int ch_end = a.nchunks, ch_step = a.nwaves, ch_begin = gw;      // interleaved: consecutive chunks go to consecutive waves
 		for (int ch = ch_begin; ch < ch_end; ch += ch_step) {
 			load_chunk<NT>(p, a.a, a.lda, (size_t)ch * 64, a.m, a.n, c, q);
 #pragma unroll
@@ -481,15 +469,12 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 // gram_bf16_kernel: the same Gram tiles on v_mfma_f32_16x16x32_bf16 with the 3-way bf16 split of both operands
 // (six exact-product terms per tile).  Every K-step (32 rows) is one MFMA chain that starts from zero; its fp32 result is
 // added to fp64 totals on the vector units, so the only fp32 roundings are those inside one chain and they average out over
-// the K-steps (2^20 rows: U(0,1) input 5.5e-7 instead of 9.2e-7, U(0,1)+10 1.5e-5 instead of 2e-4; same speed, memory-bound).
+// the K-steps (2^20 rows: U(0,1) input 5.5e-7 instead of 9.2e-7, U(0,1)+10 1.5e-5 instead of 2e-4 with fp32 totals).
 // The host accepts the result only when the Cholesky pivots show nearly orthogonal columns (chol_kernel thresholds).
-// Partials use the f32 MFMA C/D layout (row = 4*(lane>>4) + reg).  TSQR_GRAM_ACC32: the earlier fp32 totals (flush every 4 chunks).
-#ifndef TSQR_GRAM_TERMS
-#define TSQR_GRAM_TERMS 6
-#endif
-#ifndef TSQR_GRAM_FLUSH
-#define TSQR_GRAM_FLUSH 4
-#endif
+// Partials use the f32 MFMA C/D layout (row = 4*(lane>>4) + reg).
+// Measured alternatives (round 2, 2^20 x 64; tools/seq_bench.py, git history): a workgroup LDS-DMA ring (61 us: sharing a block
+// between waves duplicates the split), a per-wave LDS-DMA bounce with full-line requests and a prefetched next chunk (54.6 us)
+// against 53.6 us here: the pass is bound by vector + matrix issue at the clock the chip holds (~1.6 GHz), not by its requests.
 template <int NT>
 __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
@@ -501,29 +486,16 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	const int c = lane & 15, q = lane >> 4;
 	// the MFMA's own fp32 accumulation is biased (measured: ||Q^T Q - I|| grows with the accumulation length), so the
 	// length of an MFMA accumulation chain must not depend on m: one K-step per chain, fp64 from there on
-#ifndef TSQR_GRAM_ACC32
 	f32x4 acc[NTRI];
 	f64x4 tot[NTRI];
-#else
-	f32x4 acc[NTRI], tot[NTRI];
-#endif
 #pragma unroll
 	for (int t = 0; t < NTRI; t++) {
 		acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifndef TSQR_GRAM_ACC32
 		tot[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-#else
-		tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
 	}
 	if (gw < a.nwaves) {
 		float p[NT][16];
-#ifndef TSQR_BLOCKED_CHUNKS
 		const int ch_end = a.nchunks, ch_step = a.nwaves, ch_begin = gw;
-#else
-		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw), ch_step = 1, ch_begin = gw * a.cpw;
-#endif
-		int since_flush = 0;
 		for (int ch = ch_begin; ch < ch_end; ch += ch_step) {
 			load_chunk<NT>(p, a.a, a.lda, (size_t)ch * 64, a.m, a.n, c, q);
 #pragma unroll
@@ -535,53 +507,35 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 #pragma unroll
 					for (int jp = 0; jp < 4; jp++) {
 						unsigned h, m, lo;
-#ifdef TSQR_ABL_NOSPLIT
-						h = __builtin_bit_cast(unsigned, p[t][8 * kt + 2 * jp]); m = __builtin_bit_cast(unsigned, p[t][8 * kt + 2 * jp + 1]); lo = h ^ m;
-#else
 						split3_pair(p[t][8 * kt + 2 * jp], p[t][8 * kt + 2 * jp + 1], h, m, lo);
-#endif
 						hh[jp] = h; mm[jp] = m; ll[jp] = lo;
 					}
 					oh[t] = __builtin_bit_cast(bf16x8, hh);
 					om[t] = __builtin_bit_cast(bf16x8, mm);
 					ol[t] = __builtin_bit_cast(bf16x8, ll);
 				}
-				// smallest terms first inside each pass over the tiles; consecutive MFMAs hit different accumulators
+				// six of the nine partial products of (h+m+l)x(h+m+l), smallest first: mm hl lh hm mh hh; consecutive MFMAs hit
+				// different accumulators
 #pragma unroll
-				// the nine partial products of (h+m+l)x(h+m+l), smallest first: ll ml lm mm hl lh hm mh hh; the last TSQR_GRAM_TERMS are used
-				for (int pass = 9 - TSQR_GRAM_TERMS; pass < 9; pass++) {
+				for (int pass = 3; pass < 9; pass++) {
 					int idx = 0;
 #pragma unroll
 					for (int ti = 0; ti < NT; ti++)
 #pragma unroll
 						for (int tj = ti; tj < NT; tj++) {
-							const bf16x8 av = (pass == 4 || pass == 6 || pass == 8) ? oh[ti] : ((pass == 1 || pass == 3 || pass == 7) ? om[ti] : ol[ti]);
-							const bf16x8 bv = (pass == 5 || pass == 7 || pass == 8) ? oh[tj] : ((pass == 2 || pass == 3 || pass == 6) ? om[tj] : ol[tj]);
+							const bf16x8 av = (pass == 4 || pass == 6 || pass == 8) ? oh[ti] : ((pass == 3 || pass == 7) ? om[ti] : ol[ti]);
+							const bf16x8 bv = (pass == 5 || pass == 7 || pass == 8) ? oh[tj] : ((pass == 3 || pass == 6) ? om[tj] : ol[tj]);
 							acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[idx], 0, 0, 0);
 							idx++;
 						}
 				}
-#ifndef TSQR_GRAM_ACC32
 #pragma unroll
 				for (int t = 0; t < NTRI; t++) {
 #pragma unroll
 					for (int r = 0; r < 4; r++) tot[t][r] += (double)acc[t][r];
 					acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 				}
-#endif
 			}
-#ifdef TSQR_GRAM_ACC32
-			if (++since_flush == TSQR_GRAM_FLUSH || ch + ch_step >= ch_end) {
-				since_flush = 0;
-#pragma unroll
-				for (int t = 0; t < NTRI; t++) {
-					tot[t] += acc[t];
-					acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-				}
-			}
-#else
-			(void)since_flush;
-#endif
 		}
 	}
 	// workgroup sum in fp64: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the partial
@@ -620,28 +574,14 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	}
 }
 
-// sub[s][e] = sum of part[b][e] over b = s, s+NSPLIT, ...   (e < nelem)
-__global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ sub, const double* __restrict__ part,
-                                                          int nblocks, int nelem, int nsplit) {
-	const int e = blockIdx.x * 256 + threadIdx.x;
-	const int sidx = blockIdx.y;
-	if (e >= nelem) return;
-	double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-	int b = sidx;
-	for (; b + 3 * nsplit < nblocks; b += 4 * nsplit) {
-		s0 += part[(size_t)b * nelem + e];
-		s1 += part[(size_t)(b + nsplit) * nelem + e];
-		s2 += part[(size_t)(b + 2 * nsplit) * nelem + e];
-		s3 += part[(size_t)(b + 3 * nsplit) * nelem + e];
-	}
-	for (; b < nblocks; b += nsplit) s0 += part[(size_t)b * nelem + e];
-	sub[(size_t)sidx * nelem + e] = (s0 + s1) + (s2 + s3);
-}
-
 // gram_reduce1_kernel: partials -> G in ONE launch (deterministic: fixed partition, fixed tree).  A workgroup owns 16
 // consecutive entries; thread (e = tid & 15, s = tid >> 4) sums the partials b = s, s+16, s+32, ... of entry e with four
 // independent accumulators, then the 16 s-sums of every entry are added through LDS in a fixed pairwise tree.
-__global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ gout, const double* __restrict__ part, int nparts, int nelem) {
+// gout[nelem] receives `rows` (the local row count as a double): a row-partitioned run all-reduces nelem + 1 doubles, and the
+// Cholesky kernel then reads the GLOBAL row count for its thresholds from the same payload -- every rank takes the same verdict.
+__global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ gout, const double* __restrict__ part, int nparts, int nelem,
+                                                           double rows) {
+	if (blockIdx.x == 0 && threadIdx.x == 0) gout[nelem] = rows;
 	__shared__ double red[16][17];
 	const int e = threadIdx.x & 15, s = threadIdx.x >> 4;
 	const int el = blockIdx.x * 16 + e;
@@ -680,17 +620,6 @@ __device__ __forceinline__ double bcast_lane_f64(double x, int lane_const) {
 	return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// second reduction stage: G[e] = sum over the nsplit sub-sums (fixed order)
-__global__ __launch_bounds__(256) void gram_reduce2_kernel(double* __restrict__ gout, const double* __restrict__ sub, int nelem, int nsplit) {
-	const int e = blockIdx.x * 256 + threadIdx.x;
-	if (e >= nelem) return;
-	double v[16];
-#pragma unroll
-	for (int s = 0; s < 16; s++) v[s] = (s < nsplit) ? sub[(size_t)s * nelem + e] : 0.0;
-	gout[e] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
-	          (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
-}
-
 // Row ownership of the elimination kernels: thread (w, j) holds column j of the rows  row(w, s) = 16*(s>>2) + 4*w + (s&3),
 // i.e. every wave owns FOUR consecutive rows of each 16-row block.  A "group" = those four rows: its owner factors them
 // against each other in registers (lane broadcasts, no LDS), publishes the four finished rows, and after ONE barrier all
@@ -711,9 +640,7 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
 			double y = __builtin_amdgcn_rsq(piv);
 			y = y * (1.5 - 0.5 * piv * y * y);
-#if !defined(TSQR_CHOL_NEWTON) || TSQR_CHOL_NEWTON >= 2
 			y = y * (1.5 - 0.5 * piv * y * y);
-#endif
 			const bool live = K < n;
 			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
 			const double mk = live ? mm[u] * y : 0.0;
@@ -756,12 +683,6 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 
 // LOADG: functor e -> G tile entry e (accumulator order); host_status: optional device-visible alias of pinned host memory
 // that receives the three status words as well (the host then needs no copy operation to read them).
-#ifdef TSQR_CHOL_DBG
-__device__ long long g_chol_dbg[32];
-#define CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_dbg[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define CHOL_STAMP(i) do { } while (0)
-#endif
 template <class LOADG>
 __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
@@ -773,7 +694,6 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	const int j = t & 63, w = t >> 6;
 	const int NP = 16 * NT;
 	// issue the loads of G first (one value per thread and tile), then initialise LDS while they are in flight
-	CHOL_STAMP(0);
 	double gv[10];
 	{
 		int idx = 0;
@@ -830,11 +750,9 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	const double dgj = Gs[j * 65 + j];
 	double s_acc = 0.0;
 	__syncthreads();
-	CHOL_STAMP(1);
 #pragma unroll 1
 	for (int kk = 0; kk < 4; kk++) {
 		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, z, pv, w, j, n, NP, kk, dgj, s_acc); });
-		CHOL_STAMP(2 + kk);
 #pragma unroll
 		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
 	}
@@ -865,34 +783,60 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 				volatile unsigned* hs = host_status;
 				hs[1] = __builtin_bit_cast(unsigned, ratio);
 				hs[2] = __builtin_bit_cast(unsigned, scond);
-				hs[0] = s0;                              // uncached host memory; complete at the latest when the kernel ends
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");    // system scope: words 1, 2 are visible before the verdict word
+				hs[0] = s0;
 			}
 		}
 	}
 	// R out (fp32, exact zeros below the diagonal)
-	CHOL_STAMP(6);
 	{
 		const int i = t & 63;
 		if (i < n)
 			for (int jj = t >> 6; jj < n; jj += 4) r[(size_t)jj * ldr + i] = (i <= jj) ? Rf[i * 65 + jj] : 0.0f;
 	}
-	CHOL_STAMP(7);
 }
 
-__global__ __launch_bounds__(256) void chol_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
-                                                   const double* __restrict__ gsum, int n, int NT, int f32_layout, float min_ratio,
-                                                   float max_scond, unsigned* __restrict__ host_status, double shift_coef,
-                                                   const unsigned* __restrict__ prev_status, double min_diag) {
+struct CholArgs {
+	float* r; size_t ldr;                // R out: n x n, full block written (zeros below the diagonal)
+	float* z;                            // Z = inverse(R) out: NP x NP column-major (ld NP), zero padded
+	unsigned* status;                    // [0] 0 accepted / 1 rejected, [1] min pivot ratio (float bits), [2] S (float bits)
+	unsigned* host_status;               // optional device-visible alias of pinned host words receiving the same three values
+	const double* gsum;                  // summed Gram tiles, (tile, reg, lane) accumulator order
+	const unsigned* prev_status;         // optional: status word of the sweep this one depends on (rejected -> report rejected at once)
+	const double* rows_dev;              // optional: the row count (summed over the ranks of a row-partitioned run) as a double in
+	                                     // device memory -- overrides `rows`, so that every rank applies identical thresholds
+	double rows;                         // rows of the factored matrix: sets the bf16-level acceptance bound and the shift
+	double shift_coef;                   // > 0: shifted Cholesky, s = shift_coef * (rows * n + n (n + 1)) * trace(G)
+	int n, NT;
+	int level;                           // 2 bf16-split Gram matrix (f32 accumulator layout; pivot ratio > 2^-5, S bound, column norms >= 2^-90 rows),
+	                                     // 1 fp64 Gram matrix (f64 accumulator layout; ratio > 2^-40), 3 shifted fp64 (ratio > 0: rejects only non-finite input)
+	float scond_floor;                   // bf16 level: S <= min(128, max(scond_floor, 0.12 sqrt(rows)))
+};
+
+__global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 	// prev_status: status word of an earlier factorisation this one depends on (speculatively enqueued second sweep): when that one
 	// was rejected this one reports "rejected" at once, so that everything enqueued behind it skips as well
-	if (prev_status && prev_status[0] != 0) {
+	if (a.prev_status && a.prev_status[0] != 0) {
 		if (threadIdx.x == 0) {
-			status[0] = 1u; status[1] = 0u; status[2] = 0u;
-			if (host_status) { volatile unsigned* hs = host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
+			a.status[0] = 1u; a.status[1] = 0u; a.status[2] = 0u;
+			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
 		}
 		return;
 	}
-	chol_body(r, ldr, z, status, host_status, [&](int e) { return gsum[e]; }, n, NT, f32_layout, min_ratio, max_scond, shift_coef, min_diag);
+	const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
+	float min_ratio = 0.0f, max_scond = INFINITY;
+	double min_diag = 0.0, shift = 0.0;
+	if (a.level == 2) {
+		min_ratio = 0.03125f;
+		max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
+		min_diag = rows * 0x1p-90;
+	} else if (a.level == 1) {
+		min_ratio = 9.094947017729282e-13f;              // 2^-40
+	} else {
+		shift = a.shift_coef * (rows * (double)a.n + (double)a.n * (double)(a.n + 1));
+	}
+	chol_body(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
+	          shift, min_diag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -959,7 +903,7 @@ __global__ __launch_bounds__(256) void cross_kernel(const CrossArgs a) {
 #pragma unroll
 		for (int t = 0; t < 16; t++)
 #pragma unroll
-			for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = (double)(acc[t][r] + red[0][(t * 4 + r) * 64 + lane]);
+			for (int r = 0; r < 4; r++) part_store(&out[(t * 4 + r) * 64 + lane], (double)(acc[t][r] + red[0][(t * 4 + r) * 64 + lane]));
 	}
 }
 
@@ -1102,13 +1046,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
 
 	const int nblk = a.nchunks, nwg = a.nwaves;
-	auto blk = [&](int i) {
-#ifndef TSQR_APPLY_FORWARD
-		return nblk - 1 - i;                             // last-touched rows of A first (Infinity-Cache reuse after the R pass)
-#else
-		return i;
-#endif
-	};
+	auto blk = [&](int i) { return nblk - 1 - i; };      // (block order does not matter to the Infinity Cache: tools/seq_bench.py)
 	auto swz = [](int col) { return ((col >> 3) & 1) << 4; };
 	auto load_block = [&](f32x4 (&v)[NI], const float* base, size_t ld, int ncols, int b) {
 		const size_t row = (size_t)b * ROWS + lrow;
@@ -1348,11 +1286,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 					if constexpr (UPD) x += cin[k];
 					float* dst = a.q + (size_t)col * a.ldq + row;
 					if (row + 3 < a.m) {
-#ifndef TSQR_APPLY_CACHED_STORE
-						__builtin_nontemporal_store(x, reinterpret_cast<f32x4u*>(dst));
-#else
-						*reinterpret_cast<f32x4u*>(dst) = x;
-#endif
+						__builtin_nontemporal_store(x, reinterpret_cast<f32x4u*>(dst));      // Q must not displace A from the Infinity Cache
 					} else {
 #pragma unroll
 						for (int i = 0; i < 4; i++)
@@ -1392,7 +1326,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 #pragma unroll
 			for (int t = 0; t < NTRI; t++)
 #pragma unroll
-				for (int r = 0; r < 4; r++) out[(t * 4 + r) * 64 + lane] = gtot[t][r] + red[(t * 4 + r) * 64 + lane];
+				for (int r = 0; r < 4; r++) part_store(&out[(t * 4 + r) * 64 + lane], gtot[t][r] + red[(t * 4 + r) * 64 + lane]);
 		}
 	}
 }
@@ -1469,6 +1403,7 @@ __global__ void host_flag_kernel(unsigned* __restrict__ host_flag, unsigned seq)
 __global__ void host_status_flag_kernel(unsigned* __restrict__ host, const unsigned* __restrict__ status, unsigned seq) {
 	volatile unsigned* h = host;
 	h[0] = status[0]; h[1] = status[1]; h[2] = status[2];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope: the host must never see seq before the status words
 	h[3] = seq;
 }
 
@@ -1490,5 +1425,3 @@ __global__ __launch_bounds__(256) void zero_lower_kernel(float* __restrict__ r, 
 }
 
 }  // namespace tsqrmi
-#include "chol_wg.hip"
-#include "gram_dma.hip"

@@ -1,212 +1,222 @@
-"""Row-partitioned TSQR across the GPUs of one node (new functionality -- the reference
-has no multi-GPU path).
+"""Row-partitioned TSQR across the GPUs of one node (new functionality -- the reference has no
+multi-GPU path).  One process per GPU; rank p holds the row block A_p (the blocks may have different heights).
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank p holds the row block A_p.
+The whole factorisation of a rank is ONE call into the C ABI (tsqr_mi_qr_f32_dist / tsqr_mi_qr_f32_dist_cb, include/tsqr_mi.h):
+the same ladder as the single-GPU call, stream-ordered, with two exchange hooks
 
-Householder engine (fp32_notc; fallback of fp32_tc_cor):
-  1. R_p = fold(A_p)                    local streaming Householder TSQR         (tsqr_mi_local_r_f32)
-  2. all_gather(R_p)                    the ONLY exchange: n*n floats per rank (16 KiB at n = 64, latency-bound)
-  3. R   = fold([R_0; ...; R_{P-1}])    every rank folds the same stack -> R is bitwise identical on all ranks
-  4. Q_p = A_p * inverse(R)             local                                    (tsqr_mi_apply_rinv_f32)
-Gram engine (fp32_tc_cor, same acceptance levels as the single-GPU path):
-  1. G_p = A_p^T A_p                    local, on the matrix cores               (tsqr_mi_gram_f32)
-  2. all_reduce(G_p)                    the ONLY exchange: <= 2560 doubles (20 KiB at n = 64)
-  3. R = chol(G), Z = inverse(R)        every rank, identical input -> identical R (tsqr_mi_chol_f32); rejected -> next level
-  4. Q_p = A_p * Z                      local                                    (tsqr_mi_apply_z_f32)
-Reorthogonalize=true repeats the sweep on Q and sets R <- R2 * R.
+  Gram levels:         G_p = A_p^T A_p on the matrix cores -> all-reduce of the Gram tiles + the local row count (<= 2561
+                       doubles, ~20 KiB) -> every rank factors the SAME matrix with thresholds from the SAME global row count
+                       (identical accept / reject decisions on all ranks by construction) -> Q_p = A_p * inverse(R);
+  Householder engine:  R_p = fold(A_p) -> all-gather of the n x n factors (16 KiB per rank at n = 64, the exchange the north
+                       star names) -> every rank folds the same (P n) x n stack -> R bitwise identical -> Q_p = A_p * inverse(R).
 
-The arithmetic is behind an `engine` object so that the exchange logic can be exercised on CPU with the gloo
-backend and a test double (tests/test_dist_cpu.py); the product engine is HipEngine (C ABI, no CPU fallback).
+Transport of the hooks:
+  * RcclComm: a raw ncclComm_t created through ctypes on the librccl the process has already loaded (unique id from rank 0,
+    broadcast over torch.distributed); the C code then calls ncclAllReduce / ncclAllGather itself on the caller's stream -- no
+    Python and no host wait between the kernels of a call.  This is what bench.py --gpus N uses.
+  * TorchCollectives: callbacks into torch.distributed (any backend).  The two-process tests run the product engine with it over
+    gloo on one GPU, and bench.py falls back to it when a raw communicator cannot be created.
+
+`backend` is the object that executes the per-rank call: HipBackend (the product; no CPU fallback) or a test double with the
+same `qr_dist` signature (tests/test_dist_cpu.py drives the exchange protocol on CPU over gloo with a numpy double).
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import blockqr as bq
 
 
-class HipEngine:
-    """The product engine: staged C-ABI entry points of libtsqr_mi.so on the current HIP stream."""
+class TorchCollectives:
+    """The two exchange hooks on torch.distributed tensors (works with gloo and nccl process groups)."""
 
-    def __init__(self, mode, m_local, n, world_size, use_gram=None):
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def allreduce_f64(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, group=self.group)
+
+    def allgather_f32(self, send, recv):
+        """recv (world * send.numel()) <- concatenation of every rank's send, in rank order"""
+        k = send.numel()
+        if self.world > 1:
+            dist.all_gather([recv[i * k:(i + 1) * k] for i in range(self.world)], send, group=self.group)
+        else:
+            recv[:k].copy_(send)
+
+
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_byte * 128)]
+
+
+def _loaded_rccl_path():
+    """Path of the librccl this process has mapped (torch brings its own copy); None if there is none yet."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
+class RcclComm:
+    """Raw RCCL communicator for the C driver.  Collective over `group`: every rank must construct it at the same point."""
+
+    def __init__(self, group=None):
+        assert dist.is_initialized(), "RcclComm needs an initialised torch.distributed process group (to ship the unique id)"
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.comm = None
+        path = _loaded_rccl_path()
+        lib = None
+        for cand in ([path] if path else []) + ["librccl.so.1", "librccl.so"]:
+            try:
+                lib = ctypes.CDLL(cand)
+                break
+            except OSError:
+                continue
+        ok = lib is not None and all(hasattr(lib, s) for s in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy"))
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)     # every rank must be able to, or nobody tries
+        if int(flag.item()) == 0:
+            raise RuntimeError("librccl not loadable on every rank")
+        self._lib = lib
+        uid = _NcclUniqueId()
+        if self.rank == 0:
+            rc = lib.ncclGetUniqueId(ctypes.byref(uid))
+            if rc != 0:
+                uid = _NcclUniqueId()                  # all zeros: ncclCommInitRank then fails on every rank alike
+        buf = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(dev)
+        dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), bytes(buf.cpu().numpy().tobytes()), 128)
+        comm = ctypes.c_void_p()
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        lib.ncclCommInitRank.restype = ctypes.c_int
+        rc = lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank)
+        if rc != 0 or not comm.value:
+            raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+        self.comm = comm
+
+    def destroy(self):
+        if self.comm is not None:
+            self._lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            self._lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+_ALLREDUCE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+_ALLGATHER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class HipBackend:
+    """The product: one C-ABI call per factorisation (libtsqr_mi.so; raises if the library is missing -- no CPU fallback)."""
+
+    def __init__(self, mode, m_local, n, world, comm=None, collectives=None):
         assert n <= 64, "the row-partitioned path factors one 64-wide panel"
         self.mode = bq.compute_mode(mode)
-        self.n = n
-        self.m_local = m_local
-        # same default policy as tsqr_mi_qr_f32: bf16-split Gram level, then fp64 Gram, shifted Cholesky QR, Householder TSQR
-        self.use_gram = True if use_gram is None else bool(use_gram)
-        self.gram_levels = (2, 1)
+        self.n, self.m_local, self.world = n, m_local, world
+        L = bq.lib()
+        self.wq = torch.empty(max(L.tsqr_mi_working_q_size_dist(m_local, n, world), 1), dtype=torch.float32, device="cuda")
+        self.wr = torch.empty(max(L.tsqr_mi_working_r_size_dist(m_local, n, world), 1), dtype=torch.float32, device="cuda")
+        self.gather = torch.empty(world * n * n, dtype=torch.float32, device="cuda")
+        self.comm = comm                               # RcclComm or None
+        self.coll = collectives or TorchCollectives()
         self.last_engine = 0
-        rows = max(m_local, world_size * n)
-        self.wq = torch.empty(max(bq.get_working_q_size(rows, n), 1), dtype=torch.float32, device="cuda")
-        self.wr = torch.empty(max(bq.get_working_r_size(rows, n), 1), dtype=torch.float32, device="cuda")
-        self._g = torch.empty(bq.lib().tsqr_mi_gram_elems(n), dtype=torch.float64, device="cuda")
+        self._cb_error = None
+        self._ar = _ALLREDUCE_CB(self._allreduce)
+        self._ag = _ALLGATHER_CB(self._allgather)
 
-    def _stream(self):
-        return torch.cuda.current_stream().cuda_stream
+    # ---- callbacks: device pointers inside our own buffers -> tensor views -> torch.distributed ----
+    def _view(self, ptr, count, dtype):
+        for t in (self.wq, self.wr, self.gather):
+            base = t.data_ptr()
+            if base <= ptr < base + 4 * t.numel():
+                off = (ptr - base) // 4
+                if dtype == torch.float64:
+                    return t[off:off + 2 * count].view(torch.float64)
+                return t[off:off + count]
+        raise RuntimeError("collective on a pointer outside the engine's buffers")
 
-    def local_r(self, a, lda, m, r):
-        """r (n x n, column-major in an (n, n) tensor) <- R factor of the m x n column-major block `a`."""
-        st = bq.lib().tsqr_mi_local_r_f32(r.data_ptr(), self.n, a.data_ptr(), lda, m, self.n,
-                                          self.wq.data_ptr(), self.wr.data_ptr(), self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_local_r_f32 -> %d %s" % (st, bq.last_error()))
+    def _allreduce(self, user, buf, count, stream):
+        try:
+            self.coll.allreduce_f64(self._view(buf, count, torch.float64))
+            return 0
+        except Exception as e:                         # never let an exception cross the C frame
+            self._cb_error = e
+            return 1
 
-    def apply_rinv(self, q, ldq, a, lda, m, r):
-        st = bq.lib().tsqr_mi_apply_rinv_f32(int(self.mode), q.data_ptr(), ldq, a.data_ptr(), lda, r.data_ptr(), self.n,
-                                             m, self.n, self.wq.data_ptr(), self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_apply_rinv_f32 -> %d %s" % (st, bq.last_error()))
+    def _allgather(self, user, send, recv, count, stream):
+        try:
+            self.coll.allgather_f32(self._view(send, count, torch.float32), self._view(recv, self.world * count, torch.float32))
+            return 0
+        except Exception as e:
+            self._cb_error = e
+            return 1
 
-    def rmul(self, r, r2):
-        st = bq.lib().tsqr_mi_rmul_f32(r.data_ptr(), self.n, r2.data_ptr(), self.n, self.n, self.wq.data_ptr(), self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_rmul_f32 -> %d %s" % (st, bq.last_error()))
-
-    def gram(self, level, a, lda, m):
-        """Gram tiles of the local block in MFMA-accumulator order (float64 tensor); level 2 = bf16-split, 1 = fp64."""
-        g = self._g
-        st = bq.lib().tsqr_mi_gram_f32(level, g.data_ptr(), a.data_ptr(), lda, m, self.n,
-                                       self.wq.data_ptr(), self.wr.data_ptr(), self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_gram_f32 -> %d %s" % (st, bq.last_error()))
-        return g
-
-    def chol(self, level, g, m, r):
-        """r <- chol(G); inverse(R) stays in the work buffer for apply_z.  Returns 0 accepted / 1 rejected (blocking)."""
-        import ctypes
-        status = ctypes.c_uint(0)
-        st = bq.lib().tsqr_mi_chol_f32(level, r.data_ptr(), self.n, g.data_ptr(), m, self.n, self.wq.data_ptr(),
-                                       ctypes.byref(status), self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_chol_f32 -> %d %s" % (st, bq.last_error()))
-        return int(status.value)
-
-    def chol_async(self, level, g, m, r):
-        """Like chol() but without the stream sync: the verdict is fetched later with chol_status()."""
-        st = bq.lib().tsqr_mi_chol_f32(level, r.data_ptr(), self.n, g.data_ptr(), m, self.n, self.wq.data_ptr(), None, self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_chol_f32 -> %d %s" % (st, bq.last_error()))
-
-    def chol_status(self, m):
-        import ctypes
-        status = ctypes.c_uint(0)
-        st = bq.lib().tsqr_mi_chol_status(self.wq.data_ptr(), m, self.n, ctypes.byref(status), self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_chol_status -> %d %s" % (st, bq.last_error()))
-        return int(status.value)
-
-    def chol_shifted(self, g, m, r):
-        """r <- chol(G + s I) of the fp64 Gram tiles in g (level 3 of tsqr_mi_chol_f32); inverse(R) stays in the work buffer."""
-        import ctypes
-        status = ctypes.c_uint(0)
-        st = bq.lib().tsqr_mi_chol_f32(3, r.data_ptr(), self.n, g.data_ptr(), m, self.n, self.wq.data_ptr(),
-                                       ctypes.byref(status), self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_chol_f32(shifted) -> %d %s" % (st, bq.last_error()))
-        return int(status.value)
-
-    def wait(self):
-        """Block until everything enqueued on the current stream has completed (the single-GPU call is blocking too)."""
-        st = bq.lib().tsqr_mi_stream_wait(self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_stream_wait -> %d %s" % (st, bq.last_error()))
-
-    def apply_z(self, q, ldq, a, lda, m):
-        st = bq.lib().tsqr_mi_apply_z_f32(int(self.mode), q.data_ptr(), ldq, a.data_ptr(), lda, m, self.n,
-                                          self.wq.data_ptr(), self._stream())
-        if st != 0:
-            raise RuntimeError("tsqr_mi_apply_z_f32 -> %d %s" % (st, bq.last_error()))
-
-    def empty(self, *shape):
-        return torch.empty(*shape, dtype=torch.float32, device="cuda")
-
-
-def qr_dist(q, ldq, r, a, lda, m_local, n, engine, reorthogonalize=False, group=None):
-    """Row-partitioned QR.  a, q: column-major m_local x n blocks (tensors; q may alias a); r: (n, n) tensor receiving
-    the column-major R (identical on every rank).  Collective over `group`.  Returns state_t."""
-    if n == 0 or m_local == 0:
-        return bq.error_invalid_matrix_size
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world * m_local < n:
-        return bq.error_invalid_matrix_size
-    src, ld_src = a, lda
-    pending = False                                    # asynchronous work enqueued after the last blocking call?
-    for sweep in range(2 if reorthogonalize else 1):
-        r_new = None
-        r_shift = None
-        if getattr(engine, "use_gram", False):
-            for level in getattr(engine, "gram_levels", (2, 1)):   # bf16-split Gram, then fp64 Gram; every rank takes the same decision
-                g = engine.gram(level, src, ld_src, m_local)
-                if world > 1:
-                    dist.all_reduce(g, group=group)
-                # first sweep: factor straight into the caller's r (a rejected level is simply overwritten by the next one)
-                r_try = r if sweep == 0 else engine.empty(n, n)
-                if hasattr(engine, "chol_async") and q.data_ptr() != src.data_ptr():
-                    # the output does not alias the source: enqueue the apply speculatively behind the Cholesky and look at the
-                    # verdict afterwards -- one synchronisation per sweep, no idle gap between the two kernels
-                    engine.chol_async(level, g, m_local, r_try)
-                    engine.apply_z(q, ldq, src, ld_src, m_local)
-                    ok = engine.chol_status(m_local) == 0   # (blocking: enqueued behind the apply, so that one is complete too)
-                    pending = False
-                else:
-                    ok = engine.chol(level, g, m_local, r_try) == 0
-                    if ok:
-                        engine.apply_z(q, ldq, src, ld_src, m_local)
-                        pending = True
-                if ok:
-                    r_new = r_try
-                    engine.last_engine = max(getattr(engine, "last_engine", 0), 3 if level == 2 else 1)
-                    break
-            if r_new is None and hasattr(engine, "chol_shifted"):
-                # both Gram levels rejected (cond beyond ~1e6 or rank deficient): shifted Cholesky of the fp64 Gram matrix that is
-                # still in g (already all-reduced), Q1 = src * inverse(R1); the rest of the sweep factors Q1 in place (one plain
-                # fp64 Gram level, else the Householder engine) and R = R_second * R1
-                r_shift = engine.empty(n, n)
-                if engine.chol_shifted(g, m_local, r_shift) == 0:
-                    engine.apply_z(q, ldq, src, ld_src, m_local)
-                    pending = True
-                    src, ld_src = q, ldq
-                    g = engine.gram(1, q, ldq, m_local)
-                    if world > 1:
-                        dist.all_reduce(g, group=group)
-                    r2 = engine.empty(n, n)
-                    if engine.chol(1, g, m_local, r2) == 0 or engine.chol_shifted(g, m_local, r2) == 0:
-                        # (second alternative: Q1 still numerically rank deficient -- exactly dependent columns -- a second shifted
-                        # step keeps the result bounded, see panel_qr in csrc/tsqr_mi.hip)
-                        engine.apply_z(q, ldq, q, ldq, m_local)
-                        pending = True
-                        r_new = r2
-                        engine.last_engine = 4
-                else:
-                    r_shift = None
-            if r_new is None:
-                engine.last_engine = 2
-        if r_new is None:                              # Householder TSQR engine (on Q1 after a shifted step)
-            r_loc = engine.empty(n, n)
-            engine.local_r(src, ld_src, m_local, r_loc)
-            if world > 1:
-                gathered = [engine.empty(n, n) for _ in range(world)]
-                dist.all_gather(gathered, r_loc, group=group)
-                # column-major (world*n) x n stack: an (n, world*n) row-major tensor whose row j is column j
-                stack = torch.cat(gathered, dim=1).contiguous()
-                r_new = engine.empty(n, n)
-                engine.local_r(stack, world * n, world * n, r_new)
-            else:
-                r_new = r_loc
-            engine.apply_rinv(q, ldq, src, ld_src, m_local, r_new)
-            pending = True
-        if r_shift is not None:
-            engine.rmul(r_shift, r_new)                # R of this sweep = R_second * R1
-            r_new = r_shift
-            pending = True
-        if sweep == 0:
-            if r_new is not r:
-                r.copy_(r_new)
-                pending = True
+    def qr_dist(self, q, ldq, r, ldr, a, lda, m_local, reorth):
+        st = torch.cuda.current_stream().cuda_stream   # the callbacks issue torch work on the current stream: it must be this one
+        L = bq.lib()
+        if self.comm is not None:
+            rc = L.tsqr_mi_qr_f32_dist(int(self.mode), int(reorth), q.data_ptr(), ldq, r.data_ptr(), ldr, a.data_ptr(), lda,
+                                       m_local, self.n, self.wq.data_ptr(), self.wr.data_ptr(), self.gather.data_ptr(),
+                                       self.comm.comm, self.world, st)
         else:
-            engine.rmul(r, r_new)
-            pending = True
-        src, ld_src = q, ldq
-    if pending and hasattr(engine, "wait"):
-        engine.wait()                                  # blocking like mtk::qr::qr: complete on return
-    return bq.success_factorization
+            self._cb_error = None
+            rc = L.tsqr_mi_qr_f32_dist_cb(int(self.mode), int(reorth), q.data_ptr(), ldq, r.data_ptr(), ldr, a.data_ptr(), lda,
+                                          m_local, self.n, self.wq.data_ptr(), self.wr.data_ptr(), self.gather.data_ptr(),
+                                          self._ar, self._ag, None, self.world, st)
+            if self._cb_error is not None:
+                raise self._cb_error
+        if rc < 0:
+            raise RuntimeError("tsqr_mi_qr_f32_dist failed: %s" % bq.last_error())
+        self.last_engine = bq.last_engine()
+        return rc
+
+
+class RowPartitionedQR:
+    """mtk::qr::qr for a matrix whose rows are spread over the ranks of `group`.
+
+    comm: "auto" (raw RCCL communicator if it can be created on every rank, else torch.distributed callbacks), "rccl",
+    "callbacks", or an RcclComm instance.  backend: overrides the executor (tests)."""
+
+    def __init__(self, mode, m_local, n, group=None, comm="auto", backend=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.n, self.m_local = n, m_local
+        self.transport = "none"
+        if backend is not None:
+            self.backend = backend
+            self.transport = "test-double"
+            return
+        raw = None
+        if isinstance(comm, RcclComm):
+            raw = comm
+        elif comm in ("auto", "rccl") and self.world > 1 and dist.is_initialized():
+            try:
+                raw = RcclComm(group)
+            except Exception:
+                if comm == "rccl":
+                    raise
+                raw = None
+        self.transport = "rccl" if raw is not None else "torch.distributed callbacks"
+        self.backend = HipBackend(mode, m_local, n, self.world, comm=raw, collectives=TorchCollectives(group))
+
+    def qr(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None):
+        """q, a: column-major m_local x n blocks (tensors; q may alias a only with reorthogonalize... never for the first sweep);
+        r: (n, n) tensor receiving the column-major R, identical on every rank.  Blocking, collective.  Returns state_t."""
+        m_local = self.m_local if m_local is None else m_local
+        if self.n == 0 or m_local == 0:
+            return bq.error_invalid_matrix_size
+        return self.backend.qr_dist(q, ldq, r, self.n, a, lda, m_local, bool(reorthogonalize))
+
+    @property
+    def last_engine(self):
+        return getattr(self.backend, "last_engine", 0)
