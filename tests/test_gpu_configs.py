@@ -71,13 +71,19 @@ def test_c4_2pow23_x_64_row_partitioned_driver_one_rank(env):
     assert harness.residual(d_q, d_r, d_a, m, n) < 5e-7
 
 
+@pytest.mark.parametrize("spectrum", ["test_cond", "geometric"])
 @pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
-def test_c5_latms_cond_1e8_reorth(env, mode):
-    """C5: latms-generated 2^20 x 64 with cond 1e8 (numerically rank-deficient in fp32), Reorthogonalize = true."""
+def test_c5_latms_cond_1e8_reorth(env, mode, spectrum):
+    """C5: latms-generated 2^20 x 64 with cond 1e8 (numerically rank-deficient in fp32), Reorthogonalize = true.  Singular values as
+    the reference draws them (src/test_cond.cu:31-50: one 1/sqrt(cond), one 1, the rest U(1, sqrt(cond)) -- SURVEY 8d's default)
+    and the geometric spectrum (SURVEY 8d's second case)."""
     torch, bq, harness, oracle = env
     m, n = 1 << 20, 64
-    s = torch.logspace(0, -8, n, dtype=torch.float64)                  # geometric spectrum, cond = 1e8 (SURVEY 8d's second case)
-    d_a = harness.latms(m, n, n, s, seed=5)
+    if spectrum == "test_cond":
+        d_a = harness.get_rand_matrix_with_cond_number(m, n, 1e8, seed=5)
+    else:
+        s = torch.logspace(0, -8, n, dtype=torch.float64)
+        d_a = harness.latms(m, n, n, s, seed=5)
     st, d_q, d_r = harness.qr(d_a, m, n, bq.compute_mode[mode], True)
     assert st == 0
     assert bq.last_engine() in (1, 2, 4)                               # never the bf16-split level on such input
