@@ -163,7 +163,7 @@ def main():
     if args.backend == "gloo":                               # rehearsal: ranks may share a device
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -289,7 +289,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.mode, args.cpu_sample_rows)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

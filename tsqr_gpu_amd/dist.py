@@ -199,7 +199,7 @@ class RowPartitionedQR:
         raw = None
         if isinstance(comm, RcclComm):
             raw = comm
-        elif comm in ("auto", "rccl") and self.world > 1 and dist.is_initialized():
+        elif dist.is_initialized() and ((comm == "auto" and self.world > 1) or comm == "rccl"):
             try:
                 raw = RcclComm(group)
             except Exception:
