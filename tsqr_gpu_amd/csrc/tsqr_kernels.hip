@@ -84,6 +84,63 @@ __device__ __forceinline__ void load_chunk(float (&p)[NT][16], const float* __re
 	}
 }
 
+// ---- bf16 split helpers (shared by the fold, Gram and apply kernels) ----
+__device__ __forceinline__ unsigned f2bf(float x) {    // round-to-nearest-even bf16 bits (finite inputs)
+	const unsigned u = __builtin_bit_cast(unsigned, x);
+	return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+	h = f2bf(x);
+	const float r1 = x - __builtin_bit_cast(float, h << 16);
+	m = f2bf(r1);
+	const float r2 = r1 - __builtin_bit_cast(float, m << 16);
+	l = f2bf(r2);
+}
+
+// the same 3-way split for a PAIR of values with v_cvt_pk_bf16_f32 (RNE); results are packed MFMA operand dwords
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+	const f32x2_t v = {a, b};
+	return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+	h = cvt_pk_bf16(a, b);
+	const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+	m = cvt_pk_bf16(ra, rb);
+	const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+	l = cvt_pk_bf16(sa, sb);
+}
+
+// 3-way bf16 split of NPAIR independent pairs, written stage by stage (scheduling barriers in between) so that the
+// NPAIR dependency chains cvt -> unpack -> subtract -> cvt ... overlap instead of running back to back
+template <int NPAIR>
+__device__ __forceinline__ void split3_pairs(const float (&x)[2 * NPAIR], unsigned (&h)[NPAIR], unsigned (&m)[NPAIR], unsigned (&l)[NPAIR]) {
+	float ra[NPAIR], rb[NPAIR];
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) h[i] = cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) {
+		ra[i] = x[2 * i] - __builtin_bit_cast(float, h[i] << 16);
+		rb[i] = x[2 * i + 1] - __builtin_bit_cast(float, h[i] & 0xffff0000u);
+	}
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) m[i] = cvt_pk_bf16(ra[i], rb[i]);
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) {
+		ra[i] -= __builtin_bit_cast(float, m[i] << 16);
+		rb[i] -= __builtin_bit_cast(float, m[i] & 0xffff0000u);
+	}
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NPAIR; i++) l[i] = cvt_pk_bf16(ra[i], rb[i]);
+	__builtin_amdgcn_sched_barrier(0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // fold_kernel: streaming TPQRT.  Every wave folds `cpw` consecutive 64-row chunks of src into one
 // upper-triangular R (NP x NP, kept packed in LDS):   R <- R-factor of [R ; chunk]
@@ -93,8 +150,9 @@ __device__ __forceinline__ void load_chunk(float (&p)[NT][16], const float* __re
 // block reflector I - V T^T V^T through v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains), with every
 // operand taken from registers in the (c,q) layout -- the 16x16 transposes V needs are MFMAs against
 // identity slices.  The register tiles rotate after each panel so the same 16-step code serves all of
-// them (keeps the kernel inside the instruction cache).  All arithmetic is fp32; both compute modes
-// use this kernel (the mode only selects the MFMA engine of apply_wg_kernel).
+// them (keeps the kernel inside the instruction cache).  The panel arithmetic is fp32 in both compute modes; the block reflector
+// is applied with exact fp32 MFMA (fp32_notc, the role of reference src/tcqr32x16.cu:464-496) or with the bf16x3 error-corrected
+// MFMA products (fp32_tc_cor, the role of src/tcqr32x16.cu:228-274 + 669-819: split operands, correction products first).
 // ---------------------------------------------------------------------------------------------
 struct FoldArgs {
 	const float* src; size_t ld; size_t m; int n;     // source matrix (m x n, column-major)
@@ -102,6 +160,7 @@ struct FoldArgs {
 	float* dst; size_t dst_ld; int rows_store; int cols_store;   // wave w writes rows [w*rows_store, ...) of dst
 	int tri_init;                                     // tree levels over 64-row upper-triangular blocks: the wave's first block IS its
 	                                                  // initial R (copied, not folded), which makes a binary tree cost one fold per level
+	int cor;                                          // fp32_tc_cor: block reflectors applied with the bf16x3 error-corrected MFMA products
 };
 
 // acc += (lane 16q+K of src) * other     -- one v_fmac_f32_dpp.  FIRST=true pads the two wait states a
@@ -206,9 +265,189 @@ __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[1
 	}
 }
 
+// The same block reflector with the reference's error-corrected matrix-core arithmetic (fp32_tc_cor: reference
+// src/tcqr32x16.cu:669-819 splits H and the updated tile into fp16 hi/lo and adds the correction products first).  Here both
+// operands of the two large products are split three ways into bf16 (hi, mid, lo: 24 bits, fp32 exponent range) and multiplied on
+// v_mfma_f32_16x16x32_bf16, six products smallest first:
+//   W = W0 + V^T B : K = the 64 rows as two K-steps of 32 (registers 8kt .. 8kt+7 of both operands: the row order inside a K-step
+//                    is the same permutation on both sides, so the contraction is unaffected);
+//   B -= V W'      : K = the 16 panel columns, padded to 32: lane (row, q) contributes its own four columns 4q .. 4q+3 of -V^T
+//                    (vt, from the exact fp32-MFMA transposition) in k-slots 0..3 and zeros in 4..7, W' supplies the same slots;
+//   W' = T^T W     : 16 x 16 x 16, stays on the exact fp32 MFMA.
+// vh/vm/vl[kt]: split of V per K-step; th/tm/tl[rt]: split of the padded -V^T slices (both prepared once per panel).
+template <bool TRI>
+__device__ __forceinline__ void trail_update_cor(float (&pj)[16], const bf16x8 (&vh)[2], const bf16x8 (&vm)[2], const bf16x8 (&vl)[2],
+                                                 const bf16x8 (&th)[4], const bf16x8 (&tm)[4], const bf16x8 (&tl)[4], const float (&ta)[4],
+                                                 float* __restrict__ Rp, int K0, int colj, int NP, int c, int q, int glim) {
+	int idx[4];
+	f32x4 w0;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const int k = K0 + 4 * q + r;
+		idx[r] = k * NP - (k * (k - 1)) / 2 + (colj + c - k);
+		w0[r] = Rp[idx[r]];
+	}
+	f32x4 w = w0;                                        // W = W0 + V^T B
+#pragma unroll
+	for (int kt = 0; kt < 2; kt++)
+		if (!TRI || 2 * kt <= glim) {                    // rows 32 kt .. are zero in a triangular block beyond row tile glim
+			u32x4 hh, mm, ll;
+#pragma unroll
+			for (int jp = 0; jp < 4; jp++) {
+				unsigned h, m, lo;
+				split3_pair(pj[8 * kt + 2 * jp], pj[8 * kt + 2 * jp + 1], h, m, lo);
+				hh[jp] = h; mm[jp] = m; ll[jp] = lo;
+			}
+			const bf16x8 bh = __builtin_bit_cast(bf16x8, hh), bm = __builtin_bit_cast(bf16x8, mm), bl = __builtin_bit_cast(bf16x8, ll);
+			w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vm[kt], bm, w, 0, 0, 0);
+			w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[kt], bl, w, 0, 0, 0);
+			w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[kt], bh, w, 0, 0, 0);
+			w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[kt], bm, w, 0, 0, 0);
+			w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vm[kt], bh, w, 0, 0, 0);
+			w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[kt], bh, w, 0, 0, 0);
+		}
+	f32x4 wp = {0.f, 0.f, 0.f, 0.f};                     // W' = T^T W   (k-slot (q, r) <-> panel column 4q+r), exact fp32
+#pragma unroll
+	for (int r = 0; r < 4; r++) wp = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[r], w[r], wp, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 4; r++) Rp[idx[r]] = w0[r] - wp[r];
+	// B operand of the second product: this lane's four rows of W' in k-slots 0..3, zeros in 4..7
+	unsigned h0, m0, l0, h1, m1, l1;
+	split3_pair(wp[0], wp[1], h0, m0, l0);
+	split3_pair(wp[2], wp[3], h1, m1, l1);
+	const bf16x8 wh = __builtin_bit_cast(bf16x8, u32x4{h0, h1, 0u, 0u}), wm = __builtin_bit_cast(bf16x8, u32x4{m0, m1, 0u, 0u}),
+	             wl = __builtin_bit_cast(bf16x8, u32x4{l0, l1, 0u, 0u});
+#pragma unroll
+	for (int rt = 0; rt < 4; rt++) {                     // B -= V W'
+		if (TRI && rt > glim) continue;
+		f32x4 acc = {pj[4 * rt], pj[4 * rt + 1], pj[4 * rt + 2], pj[4 * rt + 3]};
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tm[rt], wm, acc, 0, 0, 0);
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th[rt], wl, acc, 0, 0, 0);
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tl[rt], wh, acc, 0, 0, 0);
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th[rt], wm, acc, 0, 0, 0);
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tm[rt], wh, acc, 0, 0, 0);
+		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th[rt], wh, acc, 0, 0, 0);
+		pj[4 * rt] = acc[0]; pj[4 * rt + 1] = acc[1]; pj[4 * rt + 2] = acc[2]; pj[4 * rt + 3] = acc[3];
+	}
+}
+
+// One TPQRT fold of the chunk in p (64 rows x NP columns, (c,q) layout) into the packed upper-triangular R of this wave (Rw, LDS):
+// R <- R-factor of [R ; chunk].  TRI: the chunk is itself a 64-row upper-triangular block (panel S is zero below row tile S).
+// COR: fp32_tc_cor -- the block reflector is applied with the bf16x3 error-corrected MFMA products (trail_update_cor), otherwise
+// with exact fp32 MFMA (fp32_notc).  p is consumed (the register tiles rotate).
+template <int NT, bool TRI, bool COR>
+__device__ __forceinline__ void fold_one(float (&p)[NT][16], float* __restrict__ Rw, float* __restrict__ Tl, int n, int c, int q) {
+	constexpr int NP = 16 * NT;
+	const int ntile = (n + 15) >> 4;                     // tiles that carry data
+#pragma unroll 1
+	for (int S = 0; S < ntile; S++) {
+		const int K0 = 16 * S;
+		const int glim = TRI ? S : 3;                    // triangular source block: panel S is zero below row tile S
+		float Trow[16];
+#pragma unroll
+		for (int l = 0; l < 16; l++) Trow[l] = 0.0f;
+		float sc = 1.0f;
+		int offK = K0 * NP - (K0 * (K0 - 1)) / 2;        // packed offset of entry (K0, K0)
+		float rkk = Rw[offK], rkc = Rw[offK + c];        // row K0, prefetched
+		static_for<0, 16>([&](auto kk) {
+			constexpr int KK = decltype(kk)::value;
+			const int offN = offK + NP - (K0 + KK);      // row K+1
+			float rkk_n = 0.0f, rkc_n = 0.0f;
+			if (KK < 15) { rkk_n = Rw[offN]; rkc_n = Rw[offN + c - (KK + 1)]; }   // not touched by step KK
+			if (K0 + KK < n) panel_step<KK, TRI>(p[0], Trow, sc, Rw + offK, c, rkk, rkc, glim);
+			offK = offN; rkk = rkk_n; rkc = rkc_n;
+		});
+		const int ntrail = ntile - 1 - S;
+		if (ntrail > 0) {
+#pragma unroll
+			for (int r = 0; r < 16; r++) p[0][r] *= sc;                  // V of the panel
+			if (q == 0) {
+#pragma unroll
+				for (int l = 0; l < 16; l += 4) {
+					f32x4 tv = {Trow[l], Trow[l + 1], Trow[l + 2], Trow[l + 3]};
+					*reinterpret_cast<f32x4*>(&Tl[c * 16 + l]) = tv;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			float ta[4];
+#pragma unroll
+			for (int r = 0; r < 4; r++) ta[r] = Tl[(4 * q + r) * 16 + c];
+			f32x4 vt[4];                                      // -V^T per 16-row tile via MFMA against identity slices
+#pragma unroll
+			for (int rt = 0; rt < 4; rt++) {
+				f32x4 t = {0.f, 0.f, 0.f, 0.f};
+				if (!TRI || rt <= glim) {
+#pragma unroll
+					for (int r = 0; r < 4; r++)
+						t = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][4 * rt + r], (c == 4 * q + r) ? -1.0f : 0.0f, t, 0, 0, 0);
+				}
+				vt[rt] = t;
+			}
+			if constexpr (COR) {
+				bf16x8 vh[2], vm[2], vl[2], th[4], tm[4], tl[4];
+#pragma unroll
+				for (int kt = 0; kt < 2; kt++) {
+					u32x4 hh, mm, ll;
+#pragma unroll
+					for (int jp = 0; jp < 4; jp++) {
+						unsigned h, m, lo;
+						split3_pair(p[0][8 * kt + 2 * jp], p[0][8 * kt + 2 * jp + 1], h, m, lo);
+						hh[jp] = h; mm[jp] = m; ll[jp] = lo;
+					}
+					vh[kt] = __builtin_bit_cast(bf16x8, hh); vm[kt] = __builtin_bit_cast(bf16x8, mm); vl[kt] = __builtin_bit_cast(bf16x8, ll);
+				}
+#pragma unroll
+				for (int rt = 0; rt < 4; rt++) {
+					unsigned h0, m0, l0, h1, m1, l1;
+					split3_pair(vt[rt][0], vt[rt][1], h0, m0, l0);
+					split3_pair(vt[rt][2], vt[rt][3], h1, m1, l1);
+					th[rt] = __builtin_bit_cast(bf16x8, u32x4{h0, h1, 0u, 0u});
+					tm[rt] = __builtin_bit_cast(bf16x8, u32x4{m0, m1, 0u, 0u});
+					tl[rt] = __builtin_bit_cast(bf16x8, u32x4{l0, l1, 0u, 0u});
+				}
+				static_for<1, NT>([&](auto jj) {
+					constexpr int J = decltype(jj)::value;
+					if (J <= ntrail) trail_update_cor<TRI>(p[J], vh, vm, vl, th, tm, tl, ta, Rw, K0, K0 + 16 * J, NP, c, q, glim);
+				});
+			} else {
+				static_for<1, NT>([&](auto jj) {
+					constexpr int J = decltype(jj)::value;
+					if (J <= ntrail) trail_update<TRI>(p[J], p[0], vt, ta, Rw, K0, K0 + 16 * J, NP, c, q, glim);
+				});
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+		// rotate the tiles: the next panel becomes p[0]
+		static_for<0, NT - 1>([&](auto jj) {
+			constexpr int J = decltype(jj)::value;
+#pragma unroll
+			for (int r = 0; r < 16; r++) p[J][r] = p[J + 1][r];
+		});
+	}
+}
+
+// write the packed R of a wave: lane <-> row, four columns per iteration so the LDS reads overlap
+template <int NP>
+__device__ __forceinline__ void store_packed_r(float* __restrict__ dst, size_t dst_ld, const float* __restrict__ Rw, int rows_store, int cols_store, int lane) {
+	if (lane < rows_store) {
+		const int off = lane * NP - (lane * (lane - 1)) / 2;
+		for (int col0 = 0; col0 < cols_store; col0 += 4) {
+			float v[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int col = col0 + u;
+				v[u] = (lane <= col && lane < NP && col < NP) ? Rw[off + col - lane] : 0.0f;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (col0 + u < cols_store) dst[(size_t)(col0 + u) * dst_ld + lane] = v[u];
+		}
+	}
+}
+
 // TRI: the folded blocks are 64-row upper-triangular R factors (tree levels with NT == 4): the wave's first block is copied
 // into R instead of folded and every panel skips the row tiles that are structurally zero.
-template <int NT, bool TRI = false>
+template <int NT, bool TRI = false, bool COR = false>
 __global__ __launch_bounds__(256, 2) void fold_kernel(const FoldArgs a) {
 	constexpr int NP = 16 * NT;
 	constexpr int RP = (NP * (NP + 1)) / 2 + 16;         // packed upper triangle (+ slack for masked reads)
@@ -222,7 +461,6 @@ __global__ __launch_bounds__(256, 2) void fold_kernel(const FoldArgs a) {
 	float* Rw = Rs[wv];
 	float* Tl = Ts[wv];
 	for (int i = lane; i < RP; i += 64) Rw[i] = 0.0f;
-	const int ntile = (a.n + 15) >> 4;                   // tiles that carry data
 
 	float p[NT][16];
 	const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
@@ -243,137 +481,77 @@ __global__ __launch_bounds__(256, 2) void fold_kernel(const FoldArgs a) {
 	}
 	for (int ch = ch_first; ch < ch_end; ch++) {
 		load_chunk<NT>(p, a.src, a.ld, (size_t)ch * 64, a.m, a.n, c, q);
+		fold_one<NT, TRI, COR>(p, Rw, Tl, a.n, c, q);
+	}
+	store_packed_r<NP>(a.dst + (size_t)gw * a.rows_store, a.dst_ld, Rw, a.rows_store, a.cols_store, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fold_tree_kernel: the binary R-stack reduction of the reference (src/tsqr.cu:1121-1172: one launch per level) collapsed:
+// a workgroup of 8 waves (two per SIMD: the fold needs ~200 VGPRs) reduces up to 8 * per_wave triangular 64 x 64 blocks of the stack
+// to ONE -- every wave first folds its own per_wave consecutive blocks (the first is copied), then three levels of pairwise folds run
+// inside the workgroup, the partner's packed R travelling through LDS.  2048 level-0 factors become R in three launches (128
+// workgroups, 8, 1) instead of eleven; every fold is still the latency-bound 64-step chain (11 of them on the critical path).
+// NT == 4 (49 <= n <= 64) only; narrower panels keep the per-level launches.
+// ---------------------------------------------------------------------------------------------
+struct FoldTreeArgs {
+	const float* src; size_t ld;        // stack of nblocks upper-triangular 64 x 64 blocks: block b = rows 64 b .. 64 b + 63, column-major, leading dimension ld
+	int nblocks, per_wave, n;
+	float* dst; size_t dst_ld;          // workgroup g writes its R at rows g * rows_store of dst
+	int rows_store, cols_store;
+};
+constexpr int FOLD_TREE_WAVES = 8;
+template <bool COR>
+__global__ __launch_bounds__(64 * FOLD_TREE_WAVES) void fold_tree_kernel(const FoldTreeArgs a) {
+	constexpr int NT = 4, NP = 64, WAVES = FOLD_TREE_WAVES;
+	constexpr int RP = (NP * (NP + 1)) / 2 + 16;
+	extern __shared__ __attribute__((aligned(16))) char tree_smem[];     // Rs[WAVES][RP] + Ts[WAVES][256] floats
+	float* Rs = reinterpret_cast<float*>(tree_smem);
+	float* Ts = Rs + WAVES * RP;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int c = lane & 15, q = lane >> 4;
+	float* Rw = Rs + wv * RP;
+	float* Tl = Ts + wv * 256;
+	for (int i = lane; i < RP; i += 64) Rw[i] = 0.0f;
+	const int first = (blockIdx.x * WAVES + wv) * a.per_wave;
+	const int last = min(a.nblocks, first + a.per_wave);
+	const size_t mrows = (size_t)a.nblocks * 64;
+	float p[NT][16];
+	if (first < last) {
+		load_chunk<NT>(p, a.src, a.ld, (size_t)first * 64, mrows, a.n, c, q);
+#pragma unroll
+		for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+			for (int rho = 0; rho < 16; rho++) {
+				const int row = 16 * (rho >> 2) + 4 * q + (rho & 3), col = 16 * ct + c;
+				if (col >= row) Rw[row * NP - (row * (row - 1)) / 2 + col - row] = p[ct][rho];
+			}
+		__builtin_amdgcn_wave_barrier();
+		for (int b = first + 1; b < last; b++) {
+			load_chunk<NT>(p, a.src, a.ld, (size_t)b * 64, mrows, a.n, c, q);
+			fold_one<NT, true, COR>(p, Rw, Tl, a.n, c, q);
+		}
+	}
+	// waves of this workgroup that hold a factor: those whose first block exists
+	const int wg_first = blockIdx.x * WAVES * a.per_wave;
+	const int active = min(WAVES, (max(a.nblocks - wg_first, 0) + a.per_wave - 1) / a.per_wave);
 #pragma unroll 1
-		for (int S = 0; S < ntile; S++) {
-			const int K0 = 16 * S;
-			const int glim = TRI ? S : 3;                // triangular source block: panel S is zero below row tile S
-			float Trow[16];
+	for (int s = 1; s < WAVES; s *= 2) {
+		__syncthreads();                                 // the partners' factors of this level are complete
+		if ((wv & (2 * s - 1)) == 0 && wv + s < active) {
+			const float* Rp = Rs + (wv + s) * RP;            // partner's packed upper triangle -> chunk registers
 #pragma unroll
-			for (int l = 0; l < 16; l++) Trow[l] = 0.0f;
-			float sc = 1.0f;
-			int offK = K0 * NP - (K0 * (K0 - 1)) / 2;    // packed offset of entry (K0, K0)
-			float rkk = Rw[offK], rkc = Rw[offK + c];    // row K0, prefetched
-			static_for<0, 16>([&](auto kk) {
-				constexpr int KK = decltype(kk)::value;
-				const int offN = offK + NP - (K0 + KK);  // row K+1
-				float rkk_n = 0.0f, rkc_n = 0.0f;
-				if (KK < 15) { rkk_n = Rw[offN]; rkc_n = Rw[offN + c - (KK + 1)]; }   // not touched by step KK
-				if (K0 + KK < a.n) panel_step<KK, TRI>(p[0], Trow, sc, Rw + offK, c, rkk, rkc, glim);
-				offK = offN; rkk = rkk_n; rkc = rkc_n;
-			});
-			const int ntrail = ntile - 1 - S;
-			if (ntrail > 0) {
+			for (int ct = 0; ct < NT; ct++)
 #pragma unroll
-				for (int r = 0; r < 16; r++) p[0][r] *= sc;              // V of the panel
-				if (q == 0) {
-#pragma unroll
-					for (int l = 0; l < 16; l += 4) {
-						f32x4 tv = {Trow[l], Trow[l + 1], Trow[l + 2], Trow[l + 3]};
-						*reinterpret_cast<f32x4*>(&Tl[c * 16 + l]) = tv;
-					}
+				for (int rho = 0; rho < 16; rho++) {
+					const int row = 16 * (rho >> 2) + 4 * q + (rho & 3), col = 16 * ct + c;
+					p[ct][rho] = (col >= row) ? Rp[row * NP - (row * (row - 1)) / 2 + col - row] : 0.0f;
 				}
-				__builtin_amdgcn_wave_barrier();
-				float ta[4];
-#pragma unroll
-				for (int r = 0; r < 4; r++) ta[r] = Tl[(4 * q + r) * 16 + c];
-				f32x4 vt[4];                                  // -V^T per 16-row tile via MFMA against identity slices
-#pragma unroll
-				for (int rt = 0; rt < 4; rt++) {
-					f32x4 t = {0.f, 0.f, 0.f, 0.f};
-					if (!TRI || rt <= glim) {
-#pragma unroll
-						for (int r = 0; r < 4; r++)
-							t = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][4 * rt + r], (c == 4 * q + r) ? -1.0f : 0.0f, t, 0, 0, 0);
-					}
-					vt[rt] = t;
-				}
-				static_for<1, NT>([&](auto jj) {
-					constexpr int J = decltype(jj)::value;
-					if (J <= ntrail) trail_update<TRI>(p[J], p[0], vt, ta, Rw, K0, K0 + 16 * J, NP, c, q, glim);
-				});
-				__builtin_amdgcn_wave_barrier();
-			}
-			// rotate the tiles: the next panel becomes p[0]
-			static_for<0, NT - 1>([&](auto jj) {
-				constexpr int J = decltype(jj)::value;
-#pragma unroll
-				for (int r = 0; r < 16; r++) p[J][r] = p[J + 1][r];
-			});
+			fold_one<NT, true, COR>(p, Rw, Tl, a.n, c, q);
 		}
 	}
-	// write R: lane <-> row, four columns per iteration so the LDS reads overlap (consecutive lanes -> consecutive addresses)
-	float* dst = a.dst + (size_t)gw * a.rows_store;
-	if (lane < a.rows_store) {
-		const int off = lane * NP - (lane * (lane - 1)) / 2;
-		for (int col0 = 0; col0 < a.cols_store; col0 += 4) {
-			float v[4];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const int col = col0 + u;
-				v[u] = (lane <= col && lane < NP && col < NP) ? Rw[off + col - lane] : 0.0f;
-			}
-#pragma unroll
-			for (int u = 0; u < 4; u++)
-				if (col0 + u < a.cols_store) dst[(size_t)(col0 + u) * a.dst_ld + lane] = v[u];
-		}
-	}
-}
-
-// ---- bf16 split helpers (shared by the Gram and apply kernels) ----
-__device__ __forceinline__ unsigned f2bf(float x) {    // round-to-nearest-even bf16 bits (finite inputs)
-	const unsigned u = __builtin_bit_cast(unsigned, x);
-	return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-	h = f2bf(x);
-	const float r1 = x - __builtin_bit_cast(float, h << 16);
-	m = f2bf(r1);
-	const float r2 = r1 - __builtin_bit_cast(float, m << 16);
-	l = f2bf(r2);
-}
-
-// the same 3-way split for a PAIR of values with v_cvt_pk_bf16_f32 (RNE); results are packed MFMA operand dwords
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-	const f32x2_t v = {a, b};
-	return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-	h = cvt_pk_bf16(a, b);
-	const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
-	m = cvt_pk_bf16(ra, rb);
-	const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
-	l = cvt_pk_bf16(sa, sb);
-}
-
-// 3-way bf16 split of NPAIR independent pairs, written stage by stage (scheduling barriers in between) so that the
-// NPAIR dependency chains cvt -> unpack -> subtract -> cvt ... overlap instead of running back to back
-template <int NPAIR>
-__device__ __forceinline__ void split3_pairs(const float (&x)[2 * NPAIR], unsigned (&h)[NPAIR], unsigned (&m)[NPAIR], unsigned (&l)[NPAIR]) {
-	float ra[NPAIR], rb[NPAIR];
-#pragma unroll
-	for (int i = 0; i < NPAIR; i++) h[i] = cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
-	__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-	for (int i = 0; i < NPAIR; i++) {
-		ra[i] = x[2 * i] - __builtin_bit_cast(float, h[i] << 16);
-		rb[i] = x[2 * i + 1] - __builtin_bit_cast(float, h[i] & 0xffff0000u);
-	}
-	__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-	for (int i = 0; i < NPAIR; i++) m[i] = cvt_pk_bf16(ra[i], rb[i]);
-	__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-	for (int i = 0; i < NPAIR; i++) {
-		ra[i] -= __builtin_bit_cast(float, m[i] << 16);
-		rb[i] -= __builtin_bit_cast(float, m[i] & 0xffff0000u);
-	}
-	__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-	for (int i = 0; i < NPAIR; i++) l[i] = cvt_pk_bf16(ra[i], rb[i]);
-	__builtin_amdgcn_sched_barrier(0);
+	if (wv == 0) store_packed_r<NP>(a.dst + (size_t)blockIdx.x * a.rows_store, a.dst_ld, Rw, a.rows_store, a.cols_store, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -53,6 +53,8 @@ struct Settings {
 	const int fuse_gramq = env_int("TSQR_MI_FUSE_GRAMQ", 1);     // reorth, n <= 64: the first sweep's apply kernel also accumulates Q^T Q
 	const int spec_reorth = env_int("TSQR_MI_SPEC_REORTH", 1);   // reorth, n <= 64: both sweeps enqueued speculatively
 	const int auto_sweep2 = env_int("TSQR_MI_AUTO_SWEEP2", 1);   // n <= 16 without reorth: second sweep when the first one is ill conditioned
+	const int fold_tree = env_int("TSQR_MI_FOLD_TREE", 1);       // Householder engine, 64-column panels: collapsed R-stack tree (fold_tree_kernel)
+	const int fold_cor = env_int("TSQR_MI_FOLD_COR", 1);         // Householder engine, fp32_tc_cor: error-corrected bf16x3 MFMA block reflectors
 };
 Settings g_set;
 std::atomic<unsigned> g_seq{0};                        // sequence numbers of the completion flags (any thread)
@@ -256,6 +258,7 @@ struct Ctx {
 	int gramq_cap = 0, gramq_nparts = 0;
 	bool gramq_ready = false;                            // the next bf16-level Gram request can skip its pass (partials are in place)
 	Comm comm;
+	bool fold_cor = false;                               // Householder engine: block reflectors on the error-corrected bf16x3 MFMA (fp32_tc_cor)
 	double rows_global = 0.0;                            // host's view of the global row count (the device thresholds of a row-partitioned
 	                                                     // call use the all-reduced count instead)
 	unsigned* status_dev(int s) const { return reinterpret_cast<unsigned*>(wq + L.status) + 16 * s; }
@@ -354,9 +357,14 @@ int read_status(Ctx& c, int s, unsigned* out, float* scond = nullptr, bool wait 
 template <int NT> int launch_fold(const tsqrmi::FoldArgs& a, hipStream_t st) {
 	const int blocks = (a.nwaves + 3) / 4;
 	if constexpr (NT == 4) {
-		if (a.tri_init) { hipLaunchKernelGGL((tsqrmi::fold_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a); return 0; }
+		if (a.tri_init) {
+			if (a.cor) hipLaunchKernelGGL((tsqrmi::fold_kernel<4, true, true>), dim3(blocks), dim3(256), 0, st, a);
+			else hipLaunchKernelGGL((tsqrmi::fold_kernel<4, true, false>), dim3(blocks), dim3(256), 0, st, a);
+			return 0;
+		}
 	}
-	hipLaunchKernelGGL((tsqrmi::fold_kernel<NT, false>), dim3(blocks), dim3(256), 0, st, a);
+	if (a.cor) hipLaunchKernelGGL((tsqrmi::fold_kernel<NT, false, true>), dim3(blocks), dim3(256), 0, st, a);
+	else hipLaunchKernelGGL((tsqrmi::fold_kernel<NT, false, false>), dim3(blocks), dim3(256), 0, st, a);
 	return 0;
 }
 int dispatch_fold(int NT, const tsqrmi::FoldArgs& a, hipStream_t st) {
@@ -368,11 +376,47 @@ int dispatch_fold(int NT, const tsqrmi::FoldArgs& a, hipStream_t st) {
 	}
 }
 
+// the collapsed R-stack tree (fold_tree_kernel): nblocks upper-triangular 64 x 64 blocks of `stack` -> R, ping-ponging between
+// `stack` and `other`; every launch reduces by up to FOLD_TREE_WAVES * per_wave per workgroup
+int fold_tree(Ctx& c, float* r, size_t ldr, float* stack, size_t stack_ld, int nblocks, size_t n, float* other, bool cor) {
+	constexpr int RP = (64 * 65) / 2 + 16;
+	constexpr int W = tsqrmi::FOLD_TREE_WAVES;
+	constexpr int lds = (W * RP + W * 256) * (int)sizeof(float);
+	static DevOnce attr[2];
+	if (attr[cor].need(c.dev)) {
+		HIPCHK(hipFuncSetAttribute(cor ? reinterpret_cast<const void*>(&tsqrmi::fold_tree_kernel<true>) : reinterpret_cast<const void*>(&tsqrmi::fold_tree_kernel<false>),
+		                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+		attr[cor].done(c.dev);
+	}
+	float* cur = stack; size_t cur_ld = stack_ld;
+	float* nxt = other;
+	for (;;) {
+		tsqrmi::FoldTreeArgs a{};
+		a.src = cur; a.ld = cur_ld; a.nblocks = nblocks; a.n = (int)n;
+		int wgs;
+		if (nblocks <= W * 2) { a.per_wave = (nblocks + W - 1) / W; wgs = 1; }
+		else { a.per_wave = 2; wgs = (nblocks + 2 * W - 1) / (2 * W); }
+		if (wgs == 1) { a.dst = r; a.dst_ld = ldr; a.rows_store = (int)n; a.cols_store = (int)n; }
+		else { a.dst = nxt; a.dst_ld = (size_t)wgs * 64; a.rows_store = 64; a.cols_store = 64; }
+		{
+			ProfScope ps(KC_TREE, c.st);
+			if (cor) hipLaunchKernelGGL(tsqrmi::fold_tree_kernel<true>, dim3(wgs), dim3(64 * W), lds, c.st, a);
+			else hipLaunchKernelGGL(tsqrmi::fold_tree_kernel<false>, dim3(wgs), dim3(64 * W), lds, c.st, a);
+		}
+		HIPCHK(hipGetLastError());
+		if (wgs == 1) break;
+		float* t = cur; cur = nxt; nxt = t; cur_ld = (size_t)wgs * 64;
+		nblocks = wgs;
+	}
+	return 0;
+}
+
 // R (n x n, ldr; full block written, zeros below the diagonal) of src (m x n), n <= 64: streaming Householder TSQR + fold tree.
 // stack_a / stack_b: scratch for the R stacks of even / odd levels (Plan::stack_a / stack_b floats).
 int fold_r(Ctx& c, float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n, float* stack_a, float* stack_b) {
 	const Plan p = make_plan(m, n);
 	const int NT = (int)(p.NP / 16);
+	const bool cor = c.fold_cor;
 	const float* cur = src; size_t cur_ld = ld;
 	for (int lv = 0; lv < p.nlevels; lv++) {
 		tsqrmi::FoldArgs a{};
@@ -380,6 +424,7 @@ int fold_r(Ctx& c, float* r, size_t ldr, const float* src, size_t ld, size_t m, 
 		a.n = (int)n;                                    // stacks are NP wide, only the first n columns carry data
 		a.nchunks = p.nch[lv]; a.cpw = p.cpw[lv]; a.nwaves = p.nw[lv];
 		a.tri_init = (lv > 0 && p.NP == 64) ? 1 : 0;
+		a.cor = cor ? 1 : 0;
 		if (p.nw[lv] == 1) {
 			a.dst = r; a.dst_ld = ldr; a.rows_store = (int)n; a.cols_store = (int)n;
 		} else {
@@ -392,6 +437,10 @@ int fold_r(Ctx& c, float* r, size_t ldr, const float* src, size_t ld, size_t m, 
 			dispatch_fold(NT, a, c.st);
 		}
 		HIPCHK(hipGetLastError());
+		if (lv == 0 && p.nw[0] > 1 && p.NP == 64 && g_set.fold_tree) {
+			// 64-column panels: the whole R-stack tree in one or two launches (fold_tree_kernel) instead of one launch per level
+			return fold_tree(c, r, ldr, stack_a, (size_t)p.nw[0] * 64, p.nw[0], n, stack_b, cor);
+		}
 	}
 	return 0;
 }
@@ -705,6 +754,7 @@ int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq
 // ---------------------------------------------------------------------------------------------------------------------------
 int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n) {
 	const WqLayout& L = c.L;
+	c.fold_cor = (engine == 1) && g_set.fold_cor;
 	// auto policy: every mode starts at the bf16-split Gram level (exact products, fp64 accumulation across K-steps: more accurate
 	// than any plain fp32 evaluation of A^T A, accepted only for well-conditioned panels), then the fp64 Gram level, the shifted
 	// Cholesky QR step and the Householder fold; the mode selects the MFMA engine of the apply pass.  Policy 4 skips the bf16 level.
