@@ -1020,8 +1020,9 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Panel coupling for n > 64 (block modified Gram-Schmidt between 64-column panels; replaces the two cuBLAS GEMMs of
 // reference src/blockqr.cu:92-116):
-//   cross_kernel        : S = Qb^T Ap (64 x c) on v_mfma_f32_16x16x4_f32 -- exact fp32 FMA chains in both compute modes,
-//                         both operands straight from the (c,q) registers; per-workgroup partials like the Gram engine
+//   cross_kernel        : S = Qb^T Ap (64 x c) on v_mfma_f32_16x16x32_bf16 with the 3-way split of both operands (six products per
+//                         tile, as the Gram engine: 24-bit products at 1/8 of the exact-fp32 MFMA's cycles -- 154 -> ~90 us at
+//                         2^20 x 128), both operands straight from the (c,q) registers; per-workgroup partials like the Gram engine
 //   cross_finish_kernel : summed tiles -> S into R (ldr) and -S as a 64 x 64 column-major matrix for the update
 //   apply_wg_kernel<E,4,true,ROWS> : Ap <- Ap - Qb * S   (the apply kernel with a C input and a full, non-triangular Z)
 // ---------------------------------------------------------------------------------------------
@@ -1031,7 +1032,7 @@ struct CrossArgs {
 	double* part;                        // [gridDim.x][16][256]
 };
 
-__global__ __launch_bounds__(256) void cross_kernel(const CrossArgs a) {
+__global__ __launch_bounds__(256, 2) void cross_kernel(const CrossArgs a) {
 	__shared__ float red[2][16 * 256];
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
@@ -1041,18 +1042,44 @@ __global__ __launch_bounds__(256) void cross_kernel(const CrossArgs a) {
 #pragma unroll
 	for (int t = 0; t < 16; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 	if (gw < a.nwaves) {
-		float px[4][16], py[4][16];
 		const int ch_end = min(a.nchunks, (gw + 1) * a.cpw);
 		for (int ch = gw * a.cpw; ch < ch_end; ch++) {
+			float px[4][16], py[4][16];
 			load_chunk<4>(px, a.x, a.ldx, (size_t)ch * 64, a.m, 64, c, q);
 			load_chunk<4>(py, a.y, a.ldy, (size_t)ch * 64, a.m, a.ny, c, q);
 #pragma unroll
-			for (int rho = 0; rho < 16; rho++)
+			for (int kt = 0; kt < 2; kt++) {                 // K-step of 32 rows: registers 8kt .. 8kt+7 of every lane (as gram_bf16_kernel)
+				bf16x8 xh[4], xm[4], xl[4], yh[4], ym[4], yl[4];
 #pragma unroll
-				for (int ti = 0; ti < 4; ti++)
+				for (int t = 0; t < 4; t++) {
+					u32x4 hh, mm, ll;
 #pragma unroll
-					for (int tj = 0; tj < 4; tj++)
-						acc[4 * ti + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(px[ti][rho], py[tj][rho], acc[4 * ti + tj], 0, 0, 0);
+					for (int jp = 0; jp < 4; jp++) {
+						unsigned h, m, lo;
+						split3_pair(px[t][8 * kt + 2 * jp], px[t][8 * kt + 2 * jp + 1], h, m, lo);
+						hh[jp] = h; mm[jp] = m; ll[jp] = lo;
+					}
+					xh[t] = __builtin_bit_cast(bf16x8, hh); xm[t] = __builtin_bit_cast(bf16x8, mm); xl[t] = __builtin_bit_cast(bf16x8, ll);
+#pragma unroll
+					for (int jp = 0; jp < 4; jp++) {
+						unsigned h, m, lo;
+						split3_pair(py[t][8 * kt + 2 * jp], py[t][8 * kt + 2 * jp + 1], h, m, lo);
+						hh[jp] = h; mm[jp] = m; ll[jp] = lo;
+					}
+					yh[t] = __builtin_bit_cast(bf16x8, hh); ym[t] = __builtin_bit_cast(bf16x8, mm); yl[t] = __builtin_bit_cast(bf16x8, ll);
+				}
+				// six split products per tile, smallest first (mm hl lh hm mh hh); fp32 accumulation over this wave's rows as before
+#pragma unroll
+				for (int pass = 3; pass < 9; pass++)
+#pragma unroll
+					for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+						for (int tj = 0; tj < 4; tj++) {
+							const bf16x8 av = (pass == 4 || pass == 6 || pass == 8) ? xh[ti] : ((pass == 3 || pass == 7) ? xm[ti] : xl[ti]);
+							const bf16x8 bv = (pass == 5 || pass == 7 || pass == 8) ? yh[tj] : ((pass == 3 || pass == 6) ? ym[tj] : yl[tj]);
+							acc[4 * ti + tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[4 * ti + tj], 0, 0, 0);
+						}
+			}
 		}
 	}
 	if (wv >= 2) {
@@ -1464,7 +1491,10 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 					if constexpr (UPD) x += cin[k];
 					float* dst = a.q + (size_t)col * a.ldq + row;
 					if (row + 3 < a.m) {
-						__builtin_nontemporal_store(x, reinterpret_cast<f32x4u*>(dst));      // Q must not displace A from the Infinity Cache
+						// Q must not displace A from the Infinity Cache: nontemporal.  The updated panel of a coupling step (UPD) is read
+						// again at once by its own Gram and apply passes: plain stores keep it there.
+						if constexpr (UPD) *reinterpret_cast<f32x4u*>(dst) = x;
+						else __builtin_nontemporal_store(x, reinterpret_cast<f32x4u*>(dst));
 					} else {
 #pragma unroll
 						for (int i = 0; i < 4; i++)
