@@ -1278,9 +1278,12 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 		for (int t = 0; t < NTRI; t++) gtot[t] = f64x4{0.0, 0.0, 0.0, 0.0};
 	}
 	// the first block's loads are issued before Z is staged: their HBM latency overlaps the staging work
-	f32x4 v[NI];
+	// prefetch: the next block in registers (v); 64-row blocks are small enough to keep the block after it in flight as well (v2)
+	constexpr bool DEEP = (ROWS == 64 && !UPD);
+	f32x4 v[NI], v2[DEEP ? NI : 1];
 	int bi = blockIdx.x;
 	if (bi < nblk) load_block(v, a.a, a.lda, a.n, blk(bi));
+	if constexpr (DEEP) { if (bi + nwg < nblk) load_block(v2, a.a, a.lda, a.n, blk(bi + nwg)); }
 
 	if constexpr (ENGINE == 0) {
 		float* Zs = reinterpret_cast<float*>(zbase);
@@ -1321,7 +1324,13 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 			*reinterpret_cast<f32x4*>(&As[col * RS + (lrow ^ swz(col))]) = v[k];
 		}
 		__syncthreads();                                 // (also orders the Z image on the first pass)
-		if (bi + nwg < nblk) load_block(v, a.a, a.lda, a.n, blk(bi + nwg));
+		if constexpr (DEEP) {
+#pragma unroll
+			for (int k = 0; k < NI; k++) v[k] = v2[k];
+			if (bi + 2 * nwg < nblk) load_block(v2, a.a, a.lda, a.n, blk(bi + 2 * nwg));
+		} else {
+			if (bi + nwg < nblk) load_block(v, a.a, a.lda, a.n, blk(bi + nwg));
+		}
 		f32x4 cin[UPD ? NI : 1];
 		if constexpr (UPD) load_block(cin, a.q, a.ldq, a.n_out, b);
 

@@ -44,7 +44,9 @@ struct Settings {
 	std::atomic<int> gram_level{2};      // first Gram level tried: 2 bf16-split (then fp64), 1 fp64 only
 	std::atomic<int> level0_waves{2048}, tree_cpw{4}, gram_waves{2048};
 	std::atomic<int> apply_wgs{env_int("TSQR_MI_APPLY_WGS", 0)};        // 0: as many workgroups as are resident at once
-	std::atomic<int> apply_rows{env_int("TSQR_MI_APPLY_ROWS", 128)};    // rows per workgroup block of apply_wg_kernel (128 or 256)
+	std::atomic<int> apply_rows{env_int("TSQR_MI_APPLY_ROWS", 0)};      // rows per workgroup block of apply_wg_kernel: 64 / 128 / 256, 0 = auto
+	                                                                    // (bf16x3 engine: 64 rows, four workgroups per CU and two blocks in flight
+	                                                                    //  each -- 88 vs 92 us at 2^20 x 64, 881 vs 940 us at 2^23 x 64; else 128)
 	const float bf16_scond_floor = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);
 	const int debug = env_int("TSQR_MI_DEBUG", 0);
 	const int host_status = env_int("TSQR_MI_HOST_STATUS", 1);   // Cholesky status words written straight into pinned host memory
@@ -531,7 +533,7 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 		}
 		// persistent grid: as many workgroups as are resident on the 256 CUs at once (LDS / register bound: 2 or 3 per CU);
 		// measured: the fp32-MFMA engine is slower with three per CU (132 vs 112 us)
-		per_cu_cache[c.dev].store(std::min(nb, E == 0 ? 2 : 3));
+		per_cu_cache[c.dev].store(std::min(nb, E == 0 ? 2 : (ROWS == 64 ? 4 : 3)));
 		attr.done(c.dev);
 	}
 	const size_t nblk = cdiv(a.m, (size_t)ROWS);
@@ -552,7 +554,9 @@ template <int E, int NT, bool UPD> int launch_apply_any(Ctx& c, const tsqrmi::Ap
 	if constexpr (!UPD && E != 0) {                      // (the fp32-MFMA engine's fused variant spills and loses: 0.29 vs 0.22 ms per apply)
 		if (c.gramq_part && c.gramq_cap > 0) return launch_apply_wg<E, NT, UPD, 128, true>(c, a);
 	}
-	if (g_set.apply_rows.load() == 256) return launch_apply_wg<E, NT, UPD, 256>(c, a);
+	const int rows = g_set.apply_rows.load();
+	if (rows == 256) return launch_apply_wg<E, NT, UPD, 256>(c, a);
+	if constexpr (!UPD && E == 1) { if (rows == 64 || rows == 0) return launch_apply_wg<E, NT, UPD, 64>(c, a); }
 	return launch_apply_wg<E, NT, UPD, 128>(c, a);
 }
 template <int E> int dispatch_apply_nt(Ctx& c, int NT, const tsqrmi::ApplyArgs& a) {
