@@ -804,21 +804,23 @@ __device__ __forceinline__ double bcast_lane_f64(double x, int lane_const) {
 // waves apply the four rank-1 updates to their remaining rows.  16 barriers for 64 rows; after the four groups of a block
 // the register rows rotate by four so the active block is always slots 0..3.
 template <int U>
-__device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* __restrict__ z,
-                                           double* pv, int w, int j, int n, int NP, int kk, double dgj, double& s_acc) {
+__device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* Zf,
+                                           double* pv, int w, int j, int n, int kk, double dgj, double& s_acc) {
 	const int K0 = 16 * kk + 4 * U;
 	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
 	double* rr = Rrow + (U & 1) * 256;                   // [4][64]
 	double* mr = Mrow + (U & 1) * 256;
 	if (w == U) {
+		// the owner's section is the critical path (three waves wait at the barrier): nothing but the pivots, the two row
+		// scalings, the in-group eliminations and the publication of the rows; fp32 copies, Z and the verdict sums are taken
+		// from the published rows by a wave that is off the path (below)
 		static_for<0, 4>([&](auto uu) {
 			constexpr int u = decltype(uu)::value;
 			const int K = K0 + u;
 			const double piv0 = bcast_lane_f64(g[u], K);
 			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
 			double y = __builtin_amdgcn_rsq(piv);
-			y = y * (1.5 - 0.5 * piv * y * y);
-			y = y * (1.5 - 0.5 * piv * y * y);
+			y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);      // one Newton step (v_rsq_f64 is good to ~2^-23: 2^-45 after it)
 			const bool live = K < n;
 			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
 			const double mk = live ? mm[u] * y : 0.0;
@@ -830,18 +832,24 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 			});
 			rr[u * 64 + j] = rk;
 			mr[u * 64 + j] = mk;
-			if (live) {
-				Rf[K * 65 + j] = (float)rk;
-				if (j == 0) pv[K] = piv0;
-				if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mk : 0.0f;     // Z[j][K] = M[K][j]
-				if (j <= K) s_acc = fma(dgj * mk, mk, s_acc);                        // sum of g_jj * Z[j][K]^2
-			}
+			if (j == 0 && live) pv[K] = piv0;
 		});
 	}
 	__syncthreads();
 	double rkj[4], mkc[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++) { rkj[u] = rr[u * 64 + j]; mkc[u] = mr[u * 64 + j]; }
+	if (w == ((U + 3) & 3)) {                            // the previous owner: not the next one, which is on the critical path
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int K = K0 + u;
+			if (K < n) {
+				Rf[K * 65 + j] = (float)rkj[u];
+				Zf[K * 65 + j] = (j <= K) ? (float)mkc[u] : 0.0f;                    // Z[j][K] = M[K][j]
+				if (j <= K) s_acc = fma(dgj * mkc[u], mkc[u], s_acc);                // sum of g_jj * Z[j][K]^2
+			}
+		}
+	}
 	const int nlive = 16 - 4 * kk;                       // register rows that still exist
 #pragma unroll
 	for (int s = 0; s < 16; s++) {
@@ -867,6 +875,8 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
                                           float max_scond, double shift_coef = 0.0, double min_diag = 0.0) {
 	__shared__ double Gs[64 * 65];               // symmetric G (assembly only): Gs[row * 65 + col]
 	__shared__ float Rf[64 * 65];                // R rows for the final store
+	__shared__ float Zf[64 * 65];                // rows of M = columns of Z for the final store (no global store inside the loop:
+	                                             // a workgroup barrier drains vmcnt, i.e. would wait for the store's round trip)
 	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
 	const int t = threadIdx.x;
 	const int j = t & 63, w = t >> 6;
@@ -930,7 +940,7 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	__syncthreads();
 #pragma unroll 1
 	for (int kk = 0; kk < 4; kk++) {
-		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, z, pv, w, j, n, NP, kk, dgj, s_acc); });
+		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, pv, w, j, n, kk, dgj, s_acc); });
 #pragma unroll
 		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
 	}
@@ -966,7 +976,10 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 			}
 		}
 	}
-	// R out (fp32, exact zeros below the diagonal)
+	// Z out (fp32: column K of Z = row K of M; the padding rows were zeroed at the start) and R out (fp32, exact zeros below the
+	// diagonal) from their LDS images, coalesced
+	for (int K = w; K < n; K += 4)
+		if (j < NP) z[(size_t)K * NP + j] = Zf[K * 65 + j];
 	{
 		const int i = t & 63;
 		if (i < n)
