@@ -20,8 +20,17 @@ args = ap.parse_args()
 m, n = args.m, args.n
 mode = bq.compute_mode[args.mode]
 if args.cond > 0:
-    from tsqr_gpu_amd import harness
-    d_a = harness.get_rand_matrix_with_cond_number(m, n, args.cond, seed=0)
+    # latms-style matrix with the reference's singular-value draw (src/test_cond.cu:31-50), built on the CPU so that the profile holds
+    # only the factorisation's own kernels (harness.get_rand_matrix_with_cond_number orthogonalises its factors with the engine itself)
+    import numpy as np
+    rng = np.random.default_rng(0)
+    s = np.empty(n); s[0] = 1.0 / np.sqrt(args.cond); s[-1] = 1.0
+    s[1:-1] = 1.0 + (np.sqrt(args.cond) - 1.0) * rng.random(n - 2)
+    s = np.sort(s)[::-1]
+    u, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    v, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    d_a = torch.from_numpy(np.ascontiguousarray(((u * s) @ v.T).T.astype(np.float32))).cuda()
+    del u
 else:
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     d_a = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
