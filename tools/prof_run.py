@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3: a few mtk::qr::qr calls of one workload.
-usage: prof_run.py [mode] [steps] [--m M] [--n N] [--policy P] [--reorth] [--cond C]
+usage: prof_run.py [mode] [steps] [--m M] [--n N] [--policy P] [--reorth] [--cond C] [--lda LD]
 Defaults: the headline workload (2^20 x 64, fp32_tc_cor, auto policy).  --cond: latms-style matrix with the
 reference's test_cond.cu singular-value draw (harness.get_rand_matrix_with_cond_number)."""
 import argparse, os, sys
@@ -16,6 +16,7 @@ ap.add_argument("--n", type=int, default=64)
 ap.add_argument("--policy", type=int, default=0)
 ap.add_argument("--reorth", action="store_true")
 ap.add_argument("--cond", type=float, default=0.0)
+ap.add_argument("--lda", type=int, default=0, help="leading dimension of A and Q (default m)")
 args = ap.parse_args()
 m, n = args.m, args.n
 mode = bq.compute_mode[args.mode]
@@ -34,13 +35,16 @@ if args.cond > 0:
 else:
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     d_a = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
+ld = args.lda if args.lda > m else m
+if ld > m:
+    pad = torch.zeros(n, ld, device="cuda"); pad[:, :m] = d_a; d_a = pad
 d_keep = d_a.clone()
-d_q = torch.empty(n, m, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
+d_q = torch.empty(n, ld, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
 bf = bq.buffer(mode, args.reorth); bf.allocate(m, n)
 bq.set_policy(args.policy)
 for _ in range(args.steps):
     if n > 64:
         d_a.copy_(d_keep)                            # a is overwritten for n > 64
-    assert bq.qr(d_q, m, d_r, n, d_a, m, m, n, bf) == 0
+    assert bq.qr(d_q, ld, d_r, n, d_a, ld, m, n, bf) == 0
 torch.cuda.synchronize()
 print("done engine", bq.ENGINE_NAMES.get(bq.last_engine()))

@@ -23,6 +23,12 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. makes every wave wait for its global
+// loads AND stores in flight -- a prefetch issued before the barrier, or the streaming stores of the previous block, would then be
+// waited for at every barrier.  Global data never travels between the waves of a workgroup in these kernels, so the LDS counter is
+// all a barrier has to wait for.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
 	if constexpr (I < N) {
@@ -804,7 +810,7 @@ __device__ __forceinline__ double bcast_lane_f64(double x, int lane_const) {
 // waves apply the four rank-1 updates to their remaining rows.  16 barriers for 64 rows; after the four groups of a block
 // the register rows rotate by four so the active block is always slots 0..3.
 template <int U>
-__device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* Zf,
+__device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* Zf, double* Zd,
                                            double* pv, int w, int j, int n, int kk, double dgj, double& s_acc) {
 	const int K0 = 16 * kk + 4 * U;
 	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
@@ -846,6 +852,7 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 			if (K < n) {
 				Rf[K * 65 + j] = (float)rkj[u];
 				Zf[K * 65 + j] = (j <= K) ? (float)mkc[u] : 0.0f;                    // Z[j][K] = M[K][j]
+				Zd[K * 65 + j] = (j <= K) ? mkc[u] : 0.0;                            // (fp64 image for the two-block factorisation)
 				if (j <= K) s_acc = fma(dgj * mkc[u], mkc[u], s_acc);                // sum of g_jj * Z[j][K]^2
 			}
 		}
@@ -872,8 +879,8 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 template <class LOADG>
 __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
-                                          float max_scond, double shift_coef = 0.0, double min_diag = 0.0) {
-	__shared__ double Gs[64 * 65];               // symmetric G (assembly only): Gs[row * 65 + col]
+                                          float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double* __restrict__ z64 = nullptr) {
+	__shared__ double Gs[64 * 65];               // symmetric G (assembly); afterwards the fp64 image of Z: Gs[K * 65 + j] = Z[j][K]
 	__shared__ float Rf[64 * 65];                // R rows for the final store
 	__shared__ float Zf[64 * 65];                // rows of M = columns of Z for the final store (no global store inside the loop:
 	                                             // a workgroup barrier drains vmcnt, i.e. would wait for the store's round trip)
@@ -940,7 +947,7 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	__syncthreads();
 #pragma unroll 1
 	for (int kk = 0; kk < 4; kk++) {
-		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, pv, w, j, n, kk, dgj, s_acc); });
+		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, Gs, pv, w, j, n, kk, dgj, s_acc); });
 #pragma unroll
 		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
 	}
@@ -980,6 +987,8 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	// diagonal) from their LDS images, coalesced
 	for (int K = w; K < n; K += 4)
 		if (j < NP) z[(size_t)K * NP + j] = Zf[K * 65 + j];
+	if (z64)                                             // 64 x 64, column-major with ld 64: z64[K * 64 + j] = Z[j][K]; zero beyond n
+		for (int K = w; K < 64; K += 4) z64[K * 64 + j] = (K < n && j <= K) ? Gs[K * 65 + j] : 0.0;
 	{
 		const int i = t & 63;
 		if (i < n)
@@ -1002,6 +1011,8 @@ struct CholArgs {
 	int level;                           // 2 bf16-split Gram matrix (f32 accumulator layout; pivot ratio > 2^-5, S bound, column norms >= 2^-90 rows),
 	                                     // 1 fp64 Gram matrix (f64 accumulator layout; ratio > 2^-40), 3 shifted fp64 (ratio > 0: rejects only non-finite input)
 	float scond_floor;                   // bf16 level: S <= min(128, max(scond_floor, 0.12 sqrt(rows)))
+	double* z64;                         // optional: inverse(R) in fp64 (64 x 64 column-major) -- one diagonal block of the two-block
+	int no_scond_bound;                  // factorisation of 64 < n <= 128 columns, whose conditioning verdict is taken over both blocks
 };
 
 __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
@@ -1026,8 +1037,9 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 	} else {
 		shift = a.shift_coef * (rows * (double)a.n + (double)a.n * (double)(a.n + 1));
 	}
+	if (a.no_scond_bound) max_scond = INFINITY;
 	chol_body(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
-	          shift, min_diag);
+	          shift, min_diag, a.z64);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1240,20 +1252,22 @@ struct ApplyArgs {
 // ---------------------------------------------------------------------------------------------
 // GRAMQ: additionally accumulate the Gram matrix Q^T Q of the rows this workgroup produces (bf16-split level, fp64 totals, same
 // partial format as gram_bf16_kernel) -- the second sweep of a reorthogonalisation then needs no Gram pass of its own.
-template <int ENGINE, int NT, bool UPD, int ROWS, bool GRAMQ>
+template <int ENGINE, int NT, bool UPD, int ROWS, bool GRAMQ, int NW = 4>
 __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
+	static_assert(!GRAMQ || NW == 4, "the fused Gram accumulation is written for four waves");
 	constexpr int NP = 16 * NT;
 	constexpr int RS = ROWS + 4;                         // column stride of As (floats)
 	constexpr int LPC = ROWS / 4, CPI = 64 / LPC;        // lanes per column, columns per load instruction
-	constexpr int NI = NP / (4 * CPI);                   // load instructions per wave and block
-	constexpr int SL = ROWS / 64;                        // 16-row slabs per wave
+	constexpr int NI = NP / (NW * CPI);                   // load instructions per wave and block
+	constexpr int SL = ROWS / (16 * NW);                       // 16-row slabs per wave
 	constexpr int ZS = NP + 16;
 	constexpr int KT = (NP + 31) / 32;
 	// blocks (kt, ct) of the MFMA-operand image of Z: for a triangular 64 x 64 Z the two blocks (1,0), (1,1) are zero and
 	// are not stored -- 18.4 KB instead of 24.6 KB, which lets three workgroups share a CU's LDS
-	constexpr bool COMPACT = (!UPD && NT == 4);
-	constexpr int NB = COMPACT ? 6 : KT * NT;
-	auto zblk = [](int kt, int ct) { return COMPACT ? (kt == 0 ? ct : ct + 2) : kt * NT + ct; };
+	constexpr bool COMPACT = (!UPD && (NT == 4 || NT == 8));
+	constexpr int NB = COMPACT ? KT * NT - KT * (KT - 1) : KT * NT;      // triangular: row kt keeps the blocks ct >= 2 kt
+	auto zblk = [](int kt, int ct) { return COMPACT ? kt * NT - kt * (kt - 1) + ct - 2 * kt : kt * NT + ct; };
+	auto zblk_kt = [](int b) { int kt = 0; while (COMPACT && kt + 1 < KT && b >= (kt + 1) * NT - (kt + 1) * kt) kt++; return COMPACT ? kt : b / NT; };
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* As = reinterpret_cast<float*>(smem);
 	char* zbase = smem + sizeof(float) * NP * RS;
@@ -1270,7 +1284,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 		const size_t row = (size_t)b * ROWS + lrow;
 #pragma unroll
 		for (int k = 0; k < NI; k++) {
-			const int col = (wv + 4 * k) * CPI + lcol;
+			const int col = (wv + NW * k) * CPI + lcol;
 			v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 			if (col < ncols) {
 				const float* src = base + (size_t)col * ld + row;
@@ -1292,7 +1306,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	}
 	// the first block's loads are issued before Z is staged: their HBM latency overlaps the staging work
 	// prefetch: the next block in registers (v); 64-row blocks are small enough to keep the block after it in flight as well (v2)
-	constexpr bool DEEP = (ROWS == 64 && !UPD);
+	constexpr bool DEEP = (ROWS == 64 && !UPD) || NW == 8;
 	f32x4 v[NI], v2[DEEP ? NI : 1];
 	int bi = blockIdx.x;
 	if (bi < nblk) load_block(v, a.a, a.lda, a.n, blk(bi));
@@ -1300,24 +1314,24 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 
 	if constexpr (ENGINE == 0) {
 		float* Zs = reinterpret_cast<float*>(zbase);
-		for (int idx = threadIdx.x; idx < NP * NP; idx += 256) {
+		for (int idx = threadIdx.x; idx < NP * NP; idx += 64 * NW) {
 			const int k = idx % NP, j = idx / NP;
 			Zs[k * ZS + j] = a.z[(size_t)j * NP + k];
 		}
 	} else if constexpr (ENGINE == 2) {
 		// Zh[kt][ct][lane][8] : B operand of v_mfma_f32_16x16x32_f16, one fp16 image (no correction terms)
 		_Float16* Zh = reinterpret_cast<_Float16*>(zbase);
-		for (int idx = threadIdx.x; idx < NB * 64 * 8; idx += 256) {
+		for (int idx = threadIdx.x; idx < NB * 64 * 8; idx += 64 * NW) {
 			const int jj = idx & 7, l = (idx >> 3) & 63, b = idx >> 9;
-			const int kt = COMPACT ? (b < 4 ? 0 : 1) : b / NT, ct = COMPACT ? (b < 4 ? b : b - 2) : b % NT;
+			const int kt = zblk_kt(b), ct = COMPACT ? b - (kt * NT - kt * (kt - 1)) + 2 * kt : b % NT;
 			const int k = 32 * kt + 8 * (l >> 4) + jj, j = 16 * ct + (l & 15);
 			Zh[(b * 64 + l) * 8 + jj] = (_Float16)((k < NP) ? a.z[(size_t)j * NP + k] : 0.0f);
 		}
 	} else {
 		unsigned short* Zb = reinterpret_cast<unsigned short*>(zbase);
-		for (int idx = threadIdx.x; idx < NB * 64 * 8; idx += 256) {
+		for (int idx = threadIdx.x; idx < NB * 64 * 8; idx += 64 * NW) {
 			const int jj = idx & 7, l = (idx >> 3) & 63, b = idx >> 9;
-			const int kt = COMPACT ? (b < 4 ? 0 : 1) : b / NT, ct = COMPACT ? (b < 4 ? b : b - 2) : b % NT;
+			const int kt = zblk_kt(b), ct = COMPACT ? b - (kt * NT - kt * (kt - 1)) + 2 * kt : b % NT;
 			const int k = 32 * kt + 8 * (l >> 4) + jj, j = 16 * ct + (l & 15);
 			const float v = (k < NP) ? a.z[(size_t)j * NP + k] : 0.0f;
 			unsigned h, m, lo;
@@ -1333,7 +1347,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 		const int b = blk(bi);
 #pragma unroll
 		for (int k = 0; k < NI; k++) {
-			const int col = (wv + 4 * k) * CPI + lcol;
+			const int col = (wv + NW * k) * CPI + lcol;
 			*reinterpret_cast<f32x4*>(&As[col * RS + (lrow ^ swz(col))]) = v[k];
 		}
 		__syncthreads();                                 // (also orders the Z image on the first pass)
@@ -1349,7 +1363,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 
 #pragma unroll
 		for (int s = 0; s < SL; s++) {
-			const int rb = wv * (ROWS / 4) + 16 * s;
+			const int rb = wv * (ROWS / NW) + 16 * s;
 			f32x4 acc[NT];
 #pragma unroll
 			for (int ct = 0; ct < NT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1442,11 +1456,22 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 				} else if constexpr (NT == 3) {
 					pair(I0{}, I0{}, I0{}, I1{});
 					pair(I0{}, I2{}, I1{}, I2{});
-				} else {
+				} else if constexpr (NT == 4) {
 					pair(I0{}, I0{}, I0{}, I1{});
 					pair(I0{}, I2{}, I0{}, I3{});
 					pair(I1{}, I2{}, I1{}, I3{});
 					if constexpr (UPD) pair(I1{}, I0{}, I1{}, I1{});
+				} else {
+					// triangular 128 x 128 Z: k-tile kt meets the column tiles ct >= 2 kt, taken two at a time
+					static_assert(NT == 8 && !UPD, "wide apply: 128 columns, triangular Z");
+					static_for<0, KT>([&](auto kk) {
+						constexpr int kt = decltype(kk)::value;
+						static_for<kt, NT / 2>([&](auto cc) {
+							constexpr int ct = 2 * decltype(cc)::value;
+							pair(std::integral_constant<int, kt>{}, std::integral_constant<int, ct>{},
+							     std::integral_constant<int, kt>{}, std::integral_constant<int, ct + 1>{});
+						});
+					});
 				}
 			}
 			// the result tile replaces this wave's rows of As (same swizzle): D layout col = 16ct + c, rows rb + 4q + i
@@ -1507,7 +1532,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 			const int nout = UPD ? a.n_out : a.n;
 #pragma unroll
 			for (int k = 0; k < NI; k++) {
-				const int col = (wv + 4 * k) * CPI + lcol;
+				const int col = (wv + NW * k) * CPI + lcol;
 				if (col < nout) {
 					f32x4 x = *reinterpret_cast<const f32x4*>(&As[col * RS + (lrow ^ swz(col))]);
 					if constexpr (UPD) x += cin[k];
@@ -1569,6 +1594,13 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 template <int ENGINE, int NT, bool UPD, int ROWS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void apply_wg_gramq_kernel(const ApplyArgs a) {
 	apply_wg_body<ENGINE, NT, UPD, ROWS, true>(a);
+}
+
+// 64 < n <= 128 in one pass: Q (m x n) = A (m x n) * Z with a triangular 128 x 128 Z.  Eight waves own 128-row blocks (one workgroup
+// per CU: the block and the operand image of Z fill most of its LDS); wave w multiplies rows 16 w .. 16 w + 15.
+template <int ENGINE>
+__global__ __launch_bounds__(512) void apply_wide_kernel(const ApplyArgs a) {
+	apply_wg_body<ENGINE, 8, false, 128, false, 8>(a);
 }
 
 // R <- R2 * R1 (n x n upper triangular, fp64 accumulation).  r1 is a packed copy (ld n) of the old R.

@@ -30,6 +30,7 @@
 
 #include "../../include/tsqr_mi.h"
 #include "tsqr_kernels.hip"
+#include "tsqr_wide.hip"
 #include "validate.hip"
 
 namespace {
@@ -43,6 +44,7 @@ struct Settings {
 	std::atomic<int> policy{0};          // 0 auto, 1 Householder, 2 Gram without check/fallback
 	std::atomic<int> gram_level{2};      // first Gram level tried: 2 bf16-split (then fp64), 1 fp64 only
 	std::atomic<int> level0_waves{2048}, tree_cpw{4}, gram_waves{2048};
+	std::atomic<int> wide{1};                            // 64 < n <= 128: one Cholesky-QR panel of up to 128 columns first (policy 5 turns it off)
 	std::atomic<int> apply_wgs{env_int("TSQR_MI_APPLY_WGS", 0)};        // 0: as many workgroups as are resident at once
 	std::atomic<int> apply_rows{env_int("TSQR_MI_APPLY_ROWS", 0)};      // rows per workgroup block of apply_wg_kernel: 64 / 128 / 256, 0 = auto
 	                                                                    // (bf16x3 engine: 64 rows, four workgroups per CU and two blocks in flight
@@ -180,9 +182,18 @@ GramPlan gram_plan(size_t m, size_t n) {
 	return g;
 }
 
+// extra work space of the one-panel path for 64 < n <= 128 (offsets in floats from WqLayout::wide; the doubles first, 16-byte aligned):
+// [summed tiles 36*256 + row count (+pad)][G22' 10*256][Z11 fp64 4096][Z22 fp64 4096][R12 fp64 4096] | [Z 128 x 128 fp32][Z22 fp32 4096]
+constexpr size_t WIDE_G_DOUBLES = 36 * 256 + 8;
+constexpr size_t WIDE_OFF_G2 = 2 * WIDE_G_DOUBLES, WIDE_OFF_Z1 = WIDE_OFF_G2 + 2 * 2560, WIDE_OFF_Z2 = WIDE_OFF_Z1 + 2 * 4096,
+                 WIDE_OFF_R12 = WIDE_OFF_Z2 + 2 * 4096, WIDE_OFF_ZW = WIDE_OFF_R12 + 2 * 4096, WIDE_OFF_ZF2 = WIDE_OFF_ZW + 128 * 128,
+                 WIDE_FLOATS = WIDE_OFF_ZF2 + 4096;
+constexpr int WIDE_MAX_WGS = 256;                       // gram_wide_kernel: one eight-wave workgroup per CU
+inline size_t wide_part_floats(size_t m) { return (std::min<size_t>((m + 63) / 64, WIDE_MAX_WGS) + 1) * 36 * 256 * 2; }
+
 // layout of wq (floats): [stack_b][Z: 4096][S: 4096][R1 copy: n*n][R2: n*n][r3, r4: 4096 each][summed tiles + row count][status]
 constexpr size_t GSUM_DOUBLES = 16 * 256 + 8;          // 16 tiles (coupling) or 10 (Gram) + the row-count word of a row-partitioned run
-struct WqLayout { size_t z, s, r1, r2, r3, r4, gsum, status, total; };
+struct WqLayout { size_t z, s, r1, r2, r3, r4, gsum, status, wide, total; };
 WqLayout wq_layout(size_t m, size_t n) {
 	const Plan p = make_plan(m, n);
 	WqLayout L{};
@@ -197,6 +208,8 @@ WqLayout wq_layout(size_t m, size_t n) {
 	o = (o + 63) & ~(size_t)63;
 	L.gsum = o; o += 2 * GSUM_DOUBLES;
 	L.status = o; o += 64;
+	L.wide = o;
+	if (n > PW && n <= 2 * PW) o += WIDE_FLOATS;         // the one-panel path for 64 < n <= 128 (sweep_wide)
 	L.total = o;
 	return L;
 }
@@ -255,6 +268,7 @@ struct Ctx {
 	int policy = 0, gram_level = 2;
 	int min_level = 2;                                   // lowest R-factor engine level used (2 bf16 Gram, 1 fp64 Gram, 0 Householder)
 	bool used_shift = false, used_householder = false;
+	bool wide = true;                                    // 64 < n <= 128: try the one-panel path first
 	int slot = 0, prev_slot = -1;                        // status slot of the sweep being enqueued / of the sweep it depends on (-1: none)
 	double* gramq_part = nullptr;                        // non-null: apply launches write per-workgroup Gram partials of their output there
 	int gramq_cap = 0, gramq_nparts = 0;
@@ -754,6 +768,96 @@ int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// 64 < n <= 128 as ONE Cholesky-QR panel (tsqr_wide.hip): Gram tiles of all n columns in one pass, the 128 x 128 Cholesky factor in
+// two 64 x 64 blocks, Q = A * inverse(R) in one pass.  Everything is enqueued speculatively: the verdict over both blocks lands in
+// slot c.slot (and its pinned alias), the apply pass skips itself on rejection, A is untouched (q == a is allowed: every workgroup
+// has its block in LDS before it writes).  r receives the full n x n factor.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int E> int launch_apply_wide(Ctx& c, tsqrmi::ApplyArgs a) {
+	constexpr auto kernel = &tsqrmi::apply_wide_kernel<E>;
+	constexpr size_t lds = sizeof(float) * 128 * (128 + 4) + (E == 0 ? sizeof(float) * 128 * (128 + 16) : (size_t)(E == 2 ? 1 : 3) * 20 * 512 * 2);
+	static DevOnce attr;
+	if (attr.need(c.dev)) {
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		attr.done(c.dev);
+	}
+	const size_t nblk = cdiv(a.m, (size_t)128);
+	a.nchunks = (int)nblk;
+	a.nwaves = (int)std::min<size_t>(nblk, 256);         // one workgroup of eight waves per CU
+	hipLaunchKernelGGL(kernel, dim3(a.nwaves), dim3(512), lds, c.st, a);
+	return 0;
+}
+int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, const float* a, size_t lda, size_t m, size_t n) {
+	float* w = c.wq + c.L.wide;
+	double* gsum = reinterpret_cast<double*>(w);
+	double* g2 = reinterpret_cast<double*>(w + WIDE_OFF_G2);
+	double* z64_1 = reinterpret_cast<double*>(w + WIDE_OFF_Z1);
+	double* z64_2 = reinterpret_cast<double*>(w + WIDE_OFF_Z2);
+	double* r12d = reinterpret_cast<double*>(w + WIDE_OFF_R12);
+	float* zw = w + WIDE_OFF_ZW;
+	float* zf2 = w + WIDE_OFF_ZF2;
+	const int n2 = (int)(n - PW), NT2 = (n2 + 15) / 16;
+	unsigned* st1 = c.status_dev(2); unsigned* st2 = c.status_dev(3);
+	// full 64-row blocks of a 128-column matrix go to the fast form of the Gram kernel, whatever is left (ragged last rows, or the
+	// whole matrix when n < 128) to the general form; both write per-workgroup partials, one after the other
+	const size_t nfull = (n == 2 * PW) ? m / 64 : 0, nrest = cdiv(m, 64) - nfull;
+	const int wgs_fast = (int)std::min<size_t>(nfull, WIDE_MAX_WGS), wgs_rest = (int)std::min<size_t>(nrest, WIDE_MAX_WGS);
+	const int wgs = wgs_fast + wgs_rest;
+	{
+		ProfScope ps(KC_GRAM, c.st);
+		tsqrmi::GramWideArgs ga{};
+		ga.a = a; ga.lda = lda; ga.m = m; ga.n = (int)n; ga.part = reinterpret_cast<double*>(c.wr);
+		static DevOnce attr;
+		if (attr.need(c.dev)) {
+			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GW_LDS_BYTES));
+			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GW_LDS_BYTES));
+			attr.done(c.dev);
+		}
+		if (wgs_fast) {
+			ga.blk0 = 0; ga.nblk = (int)nfull;
+			hipLaunchKernelGGL((tsqrmi::gram_wide_kernel<true>), dim3(wgs_fast), dim3(512), tsqrmi::GW_LDS_BYTES, c.st, ga);
+		}
+		if (wgs_rest) {
+			ga.blk0 = (int)nfull; ga.nblk = (int)nrest; ga.part += (size_t)wgs_fast * 36 * 256;
+			hipLaunchKernelGGL((tsqrmi::gram_wide_kernel<false>), dim3(wgs_rest), dim3(512), tsqrmi::GW_LDS_BYTES, c.st, ga);
+		}
+	}
+	HIPCHK(hipGetLastError());
+	{
+		ProfScope ps(KC_CHOL, c.st);
+		const int nelem = 36 * 256;
+		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, gsum, reinterpret_cast<const double*>(c.wr), wgs, nelem, (double)m);
+		tsqrmi::CholArgs ca{};
+		ca.r = r; ca.ldr = ldr; ca.z = c.wq + c.L.z; ca.status = st1; ca.gsum = gsum; ca.rows = (double)m;
+		ca.n = (int)PW; ca.NT = 4; ca.level = 2; ca.scond_floor = g_set.bf16_scond_floor; ca.z64 = z64_1; ca.no_scond_bound = 1;
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, ca);
+		tsqrmi::SchurArgs sa{};
+		sa.gsum = gsum; sa.z64_1 = z64_1; sa.r12d = r12d; sa.g2 = g2; sa.r = r; sa.ldr = ldr; sa.n2 = n2; sa.NT2 = NT2; sa.prev_status = st1;
+		hipLaunchKernelGGL(tsqrmi::schur_kernel, dim3(1), dim3(256), 0, c.st, sa);
+		ca.r = r + PW * ldr + PW; ca.z = zf2; ca.status = st2; ca.gsum = g2; ca.prev_status = st1;
+		ca.n = n2; ca.NT = NT2; ca.z64 = z64_2;
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, ca);
+		tsqrmi::ZWideArgs za{};
+		za.gsum = gsum; za.z64_1 = z64_1; za.z64_2 = z64_2; za.r12d = r12d; za.zw = zw; za.r = r; za.ldr = ldr; za.n = (int)n;
+		za.st1 = st1; za.st2 = st2; za.status = c.status_dev(c.slot);
+		za.host_status = c.hsig.dev ? c.hsig.dev + 4 * c.slot : nullptr;
+		za.rows = (double)m; za.scond_floor = g_set.bf16_scond_floor;
+		hipLaunchKernelGGL(tsqrmi::zwide_kernel, dim3(1), dim3(256), 0, c.st, za);
+	}
+	HIPCHK(hipGetLastError());
+	tsqrmi::ApplyArgs aa{};
+	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = zw; aa.skip_status = c.status_dev(c.slot);
+	int rc;
+	{
+		ProfScope ps(KC_APPLY, c.st);
+		rc = (engine == 0) ? launch_apply_wide<0>(c, aa) : (engine == 1 ? launch_apply_wide<1>(c, aa) : launch_apply_wide<2>(c, aa));
+	}
+	if (rc) return rc;
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // the whole factorisation (single GPU: comm inactive; row-partitioned: this rank's block)
 // ---------------------------------------------------------------------------------------------------------------------------
 int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n) {
@@ -776,7 +880,34 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 	// R-factor engine levels: 2 bf16-split Gram (memory-bound), 1 fp64 Gram, 0 Householder TSQR.  Deferred mode runs a level
 	// speculatively and steps down when chol_kernel rejected it; with check_now panel_qr escalates per panel by itself.
 	const int first_level = !use_gram ? 0 : c.gram_level;
-	for (int level = first_level; level >= 0; level--) {
+	bool wide_done = false;
+	if (c.wide && n > PW && n <= 2 * PW && may_fall_back && first_level == 2 && !c.comm.active()) {
+		// one Cholesky-QR panel over all n columns; rejected (ill conditioned) -> the 64-column panel path below, A is still intact
+		float* r1 = c.wq + L.r1; float* r2 = c.wq + L.r2;
+		unsigned st = 1u;
+		int rc = sweep_wide(c, engine, q, ldq, reorth ? r1 : r, reorth ? n : ldr, a, lda, m, n);
+		if (rc) return rc;
+		rc = read_status(c, c.slot, &st);
+		if (rc) return rc;
+		if (st == 0 && reorth) {
+			rc = sweep_wide(c, engine, q, ldq, r2, n, q, ldq, m, n);
+			if (rc) return rc;
+			rc = read_status(c, c.slot, &st);
+			if (rc) return rc;
+			if (st != 0) {                               // (Q1 is well conditioned: not expected) second sweep on the panel path
+				rc = sweep(c, engine, first_level, /*check_now=*/true, q, ldq, r2, n, q, ldq, m, n);
+				if (rc) return rc;
+				hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, c.st, r2, n, (int)n);
+			}
+			launch_rmul(r, ldr, r2, n, r1, n, n, c.st);
+			HIPCHK(hipGetLastError());
+			rc = wait_done(c);
+			if (rc) return rc;
+			st = 0;
+		}
+		wide_done = (st == 0);
+	}
+	for (int level = first_level; level >= 0 && !wide_done; level--) {
 		int rc;
 		if (!reorth) {
 			// level 0 reached in the speculative (deferred) mode: both Gram levels were rejected and the fp64 Gram matrix of A is
@@ -882,6 +1013,7 @@ void init_ctx(Ctx& c, void* wq, void* wr, size_t m_layout, size_t n, void* strea
 	c.L = wq_layout(m_layout, n);
 	c.policy = g_set.policy.load();
 	c.gram_level = g_set.gram_level.load();
+	c.wide = g_set.wide.load() != 0;
 }
 
 size_t working_r_need(size_t m, size_t n) {
@@ -891,6 +1023,7 @@ size_t working_r_need(size_t m, size_t n) {
 		need = std::max(need, gram_plan(m, std::min(PW, n - P)).part_floats);
 		if (n > PW) need = std::max(need, (size_t)gram_plan(m, PW).nblocks * 16 * 256 * 2);
 	}
+	if (n > PW && n <= 2 * PW) need = std::max(need, wide_part_floats(m));
 	return need;
 }
 
@@ -956,7 +1089,8 @@ int tsqr_mi_profile_read(double* ms, long* launches, int max_classes) {
 
 void tsqr_mi_set_policy(int policy) {
 	switch (policy) {
-		case 0: g_set.policy = 0; g_set.gram_level = 2; break;    // auto
+		case 0: g_set.policy = 0; g_set.gram_level = 2; g_set.wide = 1; break;    // auto
+		case 5: g_set.policy = 0; g_set.gram_level = 2; g_set.wide = 0; break;    // auto, 64-column panels only (no one-panel path for n <= 128)
 		case 1: g_set.policy = 1; g_set.gram_level = 2; break;    // always Householder TSQR
 		case 2: g_set.policy = 2; g_set.gram_level = 1; break;    // always fp64 Gram (no fallback)
 		case 3: g_set.policy = 2; g_set.gram_level = 2; break;    // always bf16-split Gram (no check, no fallback)

@@ -1,0 +1,457 @@
+// tsqr_wide.hip -- 64 < n <= 128 columns factored as ONE Cholesky-QR panel (included by tsqr_mi.hip behind tsqr_kernels.hip).
+//
+// The panel path couples two 64-column panels by block Gram-Schmidt (cross_kernel + update + second Gram pass: seven passes over
+// panel-sized data, 2.95 GB at 2^20 x 128).  For a well-conditioned matrix the same factorisation is
+//     G = A^T A (128 x 128)  ->  R = chol(G) in two 64 x 64 blocks  ->  Q = A * inverse(R)
+// with ONE read of A for G and one read + one write for Q (1.6 GB):
+//   gram_wide_kernel   : all 36 Gram tiles of a 64-row x 128-column block; the block is split ONCE into its three bf16 images in LDS
+//                        and every wave takes nine tile pairs (tile rows w and 7-w) with both MFMA operands read from LDS
+//   chol_kernel        : G11 -> R11, Z11 (fp32 + fp64)                              [existing kernel, block 1]
+//   schur_kernel       : R12 = Z11^T G12,  G22' = G22 - R12^T R12   (fp64)
+//   chol_kernel        : G22' -> R22, Z22                                           [block 2]
+//   zwide_kernel       : Z12 = -Z11 R12 Z22, the 128 x 128 Z for the apply pass, the verdict over BOTH blocks
+//                        (scaled conditioning S with the ORIGINAL diagonal of G, pivot ratios), zeros below the diagonal of R
+//   apply_wide_kernel  : Q = A * Z  (tsqr_kernels.hip)
+// The acceptance rule is the bf16-split Gram level's; a rejected factorisation leaves A untouched and the
+// caller falls back to the panel path.  Plays the role of reference src/blockqr.cu:45-178 for two panels at once.
+namespace tsqrmi {
+
+struct GramWideArgs {
+	const float* a; size_t lda; size_t m; int n;
+	int blk0, nblk;                      // this launch covers the 64-row blocks blk0 .. blk0 + nblk - 1
+	double* part;                        // [gridDim.x][36][256] doubles, tile order of wide_tile() below
+	const unsigned* skip_status;
+};
+
+// destination tile of the pair (ti, tj), ti <= tj, in the summed array: [G11: 10 tiles, NT = 4 order][G22: 10 tiles][G12: 16 tiles row-major]
+// -- the two diagonal blocks are then directly chol_kernel inputs
+__host__ __device__ constexpr int tri4(int ti, int tj) { return ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti); }
+__host__ __device__ constexpr int wide_tile(int ti, int tj) {
+	return (tj < 4) ? tri4(ti, tj) : ((ti >= 4) ? 10 + tri4(ti - 4, tj - 4) : 20 + ti * 4 + (tj - 4));
+}
+constexpr int WIDE_TILES = 36;
+constexpr int WIDE_G22 = 10 * 256, WIDE_G12 = 20 * 256;   // offsets (doubles) into the summed array
+constexpr int GW_CS = 36;                                // column stride of a bf16 image in dwords: 64 rows (32 dwords) + 4 of padding
+
+// Work split of the 36 tile pairs over four wave roles, nine pairs each, chosen so that a role touches few distinct column tiles
+// (every tile costs three 16-byte LDS reads per lane and K-step: 63 tile reads for all four roles instead of 102 with a row-wise
+// split -- the operand reads from LDS, not the MFMAs, bound this kernel):
+//   role 0: rows {0,1,2} x columns {5,6,7}      role 1: rows {0,1,2} x columns {2,3,4}
+//   role 2: rows {3,4} x columns {3..7}          role 3: the triangles of {5,6,7} and of {0,1}
+// A role keeps up to three "row" tiles resident in registers (three bf16 images each) and streams its column tiles one at a time;
+// a diagonal pair takes both operands from the streamed tile.
+struct WideRole {
+	int nres; int res[3];                // resident row tiles
+	int ncol; int col[5];                // streamed column tiles
+	int pa[9]; int pb[9];                // pair p = (row tile pa[p], column tile col[pb[p]]), pa[p] = index into res, or -1: the column tile itself
+};
+__host__ __device__ constexpr WideRole wide_role(int w) {
+	return w == 0 ? WideRole{3, {0, 1, 2}, 3, {5, 6, 7, 0, 0}, {0, 1, 2, 0, 1, 2, 0, 1, 2}, {0, 0, 0, 1, 1, 1, 2, 2, 2}}
+	     : w == 1 ? WideRole{3, {0, 1, 2}, 3, {2, 3, 4, 0, 0}, {0, 1, -1, 0, 1, 2, 0, 1, 2}, {0, 0, 0, 1, 1, 1, 2, 2, 2}}
+	     : w == 2 ? WideRole{2, {3, 4, 0}, 5, {3, 4, 5, 6, 7}, {-1, 0, -1, 0, 1, 0, 1, 0, 1}, {0, 1, 1, 2, 2, 3, 3, 4, 4}}
+	              : WideRole{3, {5, 6, 0}, 5, {5, 6, 7, 0, 1}, {-1, 0, -1, 0, 1, -1, -1, 2, -1}, {0, 1, 1, 2, 2, 2, 3, 4, 4}};
+}
+__host__ __device__ constexpr int wide_role_ti(int w, int p) { const WideRole R = wide_role(w); return R.pa[p] < 0 ? R.col[R.pb[p]] : R.res[R.pa[p]]; }
+__host__ __device__ constexpr int wide_role_tj(int w, int p) { const WideRole R = wide_role(w); return R.col[R.pb[p]]; }
+
+// the MFMA section of role W for one K-step (32 rows) of the block whose images start at `img`
+template <int W>
+__device__ __forceinline__ void gram_wide_step(f32x4 (&acc)[9], const unsigned* __restrict__ img, int ks, int lane) {
+	constexpr WideRole R = wide_role(W);
+	constexpr int IMG = 128 * GW_CS;                     // dwords per image
+	const int c = lane & 15, q = lane >> 4;
+	const unsigned* base = &img[c * GW_CS + 16 * ks + 4 * q];
+	bf16x8 rh[R.nres], rm[R.nres], rl[R.nres];
+	static_for<0, R.nres>([&](auto tt) {
+		constexpr int t = decltype(tt)::value;
+		const unsigned* src = base + 16 * R.res[t] * GW_CS;
+		rh[t] = *reinterpret_cast<const bf16x8*>(src);
+		rm[t] = *reinterpret_cast<const bf16x8*>(src + IMG);
+		rl[t] = *reinterpret_cast<const bf16x8*>(src + 2 * IMG);
+	});
+	static_for<0, R.ncol>([&](auto bb) {
+		constexpr int b = decltype(bb)::value;
+		const unsigned* src = base + 16 * R.col[b] * GW_CS;
+		const bf16x8 bh = *reinterpret_cast<const bf16x8*>(src);
+		const bf16x8 bm = *reinterpret_cast<const bf16x8*>(src + IMG);
+		const bf16x8 bl = *reinterpret_cast<const bf16x8*>(src + 2 * IMG);
+		// six of the nine partial products, smallest first: mm hl lh hm mh hh (as gram_bf16_kernel)
+		static_for<3, 9>([&](auto pp) {
+			constexpr int pass = decltype(pp)::value;
+			static_for<0, 9>([&](auto ii) {
+				constexpr int p = decltype(ii)::value;
+				if constexpr (R.pb[p] == b) {
+					constexpr int ta = R.pa[p];
+					bf16x8 ah_, am_, al_;
+					if constexpr (ta < 0) { ah_ = bh; am_ = bm; al_ = bl; }
+					else { ah_ = rh[ta]; am_ = rm[ta]; al_ = rl[ta]; }
+					const bf16x8 av = (pass == 4 || pass == 6 || pass == 8) ? ah_ : ((pass == 3 || pass == 7) ? am_ : al_);
+					const bf16x8 bv = (pass == 5 || pass == 7 || pass == 8) ? bh : ((pass == 3 || pass == 6) ? bm : bl);
+					acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[p], 0, 0, 0);
+				}
+			});
+		});
+	});
+}
+
+// Eight waves, one workgroup per CU.  A 64-row x 128-column block is split ONCE into its three bf16 images in LDS (double buffered:
+// one barrier per block, and that barrier waits for LDS only); waves 0-3 take the first 32 rows (K-step), waves 4-7 the second, wave
+// role = wave & 3.  Two blocks per workgroup are kept in flight in registers; the register sets rotate by unrolling, never by moves
+// (a move waits for the loads still in flight), and the loads of a full block are unconditional and back to back (a join between
+// them makes the compiler wait for each load before it issues the next).  Measured at 2^20 x 128 (537 MB, beyond the Infinity
+// Cache): 137 us = 3.9 TB/s; the loads alone take 130 us in this geometry.
+// FAST: every block is full (64 rows inside the matrix, n == 128).  !FAST: the general form (ragged rows, n < 128), one block in
+// flight -- the host sends only what FAST cannot take there.
+constexpr int GW_LDS_BYTES = 2 * 3 * 128 * GW_CS * 4;
+template <bool FAST>
+__global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned gw_img[];    // [buffer][image hi / mid / lo][column][row pair]
+	if (a.skip_status && a.skip_status[0] != 0) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the per-role MFMA sections are scalar branches
+	const int role = wv & 3, ks = wv >> 2;
+	const int lcol = lane >> 4, lrow = 4 * (lane & 15);
+	constexpr int IMG = 128 * GW_CS;
+	f32x4 acc[9];
+	f64x4 tot[9];
+#pragma unroll
+	for (int t = 0; t < 9; t++) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[t] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+	auto load_block = [&](f32x4 (&v)[4], int b) {
+		if constexpr (FAST) {
+			// (no branch at all: past the end the last block is simply loaded again and never used)
+			const size_t row = (size_t)(a.blk0 + min(b, a.nblk - 1)) * 64 + lrow;
+			const float* src = a.a + (size_t)(4 * wv + lcol) * a.lda + row;
+#pragma unroll
+			for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const f32x4u*>(src + (size_t)(32 * k) * a.lda);
+		} else {
+			const size_t row = (size_t)(a.blk0 + b) * 64 + lrow;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const int col = (wv + 8 * k) * 4 + lcol;     // one instruction of a wave: 4 columns x 256 contiguous bytes
+				v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+				if (b < a.nblk && col < a.n) {
+					const float* src = a.a + (size_t)col * a.lda + row;
+					if (row + 3 < a.m) v[k] = *reinterpret_cast<const f32x4u*>(src);
+					else {
+#pragma unroll
+						for (int i = 0; i < 4; i++)
+							if (row + i < a.m) v[k][i] = src[i];
+					}
+				}
+			}
+		}
+	};
+	const int step = gridDim.x;
+	int bi = blockIdx.x, it = 0;
+	auto split_block = [&](const f32x4 (&v)[4], unsigned* buf) {
+		// split the block once: thread (column, four rows) -> two dwords per image
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int col = (wv + 8 * k) * 4 + lcol;
+			unsigned h0, m0, l0, h1, m1, l1;
+			split3_pair(v[k][0], v[k][1], h0, m0, l0);
+			split3_pair(v[k][2], v[k][3], h1, m1, l1);
+			unsigned* dst = &buf[col * GW_CS + (lrow >> 1)];
+			*reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+			*reinterpret_cast<uint2*>(dst + IMG) = uint2{m0, m1};
+			*reinterpret_cast<uint2*>(dst + 2 * IMG) = uint2{l0, l1};
+		}
+	};
+	auto products = [&](const unsigned* buf) {
+		// the MFMA's own fp32 accumulation is biased over long chains: one chain per K-step, fp64 totals (as gram_bf16_kernel)
+		switch (role) {
+			case 0: gram_wide_step<0>(acc, buf, ks, lane); break;
+			case 1: gram_wide_step<1>(acc, buf, ks, lane); break;
+			case 2: gram_wide_step<2>(acc, buf, ks, lane); break;
+			default: gram_wide_step<3>(acc, buf, ks, lane); break;
+		}
+#pragma unroll
+		for (int t = 0; t < 9; t++) {
+#pragma unroll
+			for (int r = 0; r < 4; r++) tot[t][r] += (double)acc[t][r];
+			acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+		}
+	};
+	// Two register sets X, Y and two image buffers.  The loop is rotated so that its head sits between "split of the next block"
+	// and "barrier": there the only loads in flight are those of one set on every path into the head, and each wait inside the body
+	// follows the issue of the other set in straight-line code -- the compiler's (positional) wait counters then let exactly the
+	// younger set stay in flight instead of draining everything.  (The empty asm statements keep the sets from being interleaved.)
+	f32x4 vx[4], vy[4];
+	load_block(vx, bi);
+	asm volatile("" ::: "memory");
+	load_block(vy, bi + step);
+	asm volatile("" ::: "memory");
+	if (bi < a.nblk) split_block(vx, gw_img);
+	while (bi < a.nblk) {
+		lds_barrier();                                   // images of block `bi` complete; every wave is done with the other buffer
+		load_block(vx, bi + 2 * step);
+		asm volatile("" ::: "memory");
+		products(gw_img + (it & 1) * 3 * IMG);
+		bi += step; it++;
+		if (bi >= a.nblk) break;
+		split_block(vy, gw_img + (it & 1) * 3 * IMG);
+		lds_barrier();
+		load_block(vy, bi + 2 * step);
+		asm volatile("" ::: "memory");
+		products(gw_img + (it & 1) * 3 * IMG);
+		bi += step; it++;
+		if (bi >= a.nblk) break;
+		split_block(vx, gw_img + (it & 1) * 3 * IMG);
+	}
+	// the two K-halves of every tile meet through LDS (fp64), then the role's nine tiles go to the workgroup's partial
+	__syncthreads();
+	double* red = reinterpret_cast<double*>(gw_img);     // [role][9][4][64]
+	if (ks == 1) {
+#pragma unroll
+		for (int t = 0; t < 9; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[((role * 9 + t) * 4 + r) * 64 + lane] = tot[t][r];
+	}
+	__syncthreads();
+	if (ks == 0) {
+		double* out = a.part + (size_t)blockIdx.x * WIDE_TILES * 256;
+#pragma unroll
+		for (int t = 0; t < 9; t++) {
+			const int ti = role == 0 ? wide_role_ti(0, t) : (role == 1 ? wide_role_ti(1, t) : (role == 2 ? wide_role_ti(2, t) : wide_role_ti(3, t)));
+			const int tj = role == 0 ? wide_role_tj(0, t) : (role == 1 ? wide_role_tj(1, t) : (role == 2 ? wide_role_tj(2, t) : wide_role_tj(3, t)));
+			const int dst = wide_tile(ti, tj);
+#pragma unroll
+			for (int r = 0; r < 4; r++) part_store(&out[(dst * 4 + r) * 64 + lane], tot[t][r] + red[((role * 9 + t) * 4 + r) * 64 + lane]);
+		}
+	}
+}
+
+// schur_kernel: one workgroup.  R12 = Z11^T G12 (64 x n2) and G22' = G22 - R12^T R12, both in fp64 with 4 x 4 register blocks.
+//   gsum : the summed tiles ([G11][G22][G12], f32 accumulator layout: row = 4 (lane >> 4) + reg, col = lane & 15)
+//   z64_1: inverse(R11), column-major ld 64 (chol_kernel)
+//   r12d : R12 out, r12d[i * 64 + j] (row i of R12 contiguous)
+//   g2   : G22' out in the accumulator order chol_kernel reads: the tiles (ti <= tj < NT2) packed row by row
+//   r    : the caller's R; R12 is written to its block (rows 0..63, columns 64..64+n2)
+struct SchurArgs {
+	const double* gsum; const double* z64_1; double* r12d; double* g2; float* r; size_t ldr; int n2; int NT2;
+	const unsigned* prev_status;
+};
+__global__ __launch_bounds__(256) void schur_kernel(const SchurArgs a) {
+	__shared__ double Zs[64 * 68];                       // Zs[k * 68 + i] = Z11[k][i]   (then R12: Rs[i * 68 + j])
+	__shared__ double Gd[64 * 68];                       // Gd[k * 68 + j] = G12[k][j]
+	if (a.prev_status && a.prev_status[0] != 0) return;
+	const int t = threadIdx.x;
+	for (int e = t; e < 64 * 64; e += 256) {
+		const int k = e & 63, i = e >> 6;                // z64_1[i * 64 + k] = Z11[k][i]
+		Zs[k * 68 + i] = a.z64_1[e];
+	}
+	for (int e = t; e < 16 * 256; e += 256) {
+		const int tile = e >> 8, reg = (e >> 6) & 3, l = e & 63;
+		const int row = 16 * (tile >> 2) + 4 * (l >> 4) + reg, col = 16 * (tile & 3) + (l & 15);
+		Gd[row * 68 + col] = a.gsum[WIDE_G12 + e];
+	}
+	__syncthreads();
+	const int ib = t >> 4, jb = t & 15;
+	double acc[4][4];
+#pragma unroll
+	for (int x = 0; x < 4; x++)
+#pragma unroll
+		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
+	// R12[i][j] = sum_{k <= i} Z11[k][i] G12[k][j]
+#pragma unroll 4
+	for (int k = 0; k <= 4 * ib + 3; k++) {
+		double zi[4], gj[4];
+#pragma unroll
+		for (int x = 0; x < 4; x++) { zi[x] = Zs[k * 68 + 4 * ib + x]; gj[x] = Gd[k * 68 + 4 * jb + x]; }
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+#pragma unroll
+			for (int y = 0; y < 4; y++) acc[x][y] = fma(zi[x], gj[y], acc[x][y]);
+	}
+	__syncthreads();
+	double* Rs = Zs;
+#pragma unroll
+	for (int x = 0; x < 4; x++)
+#pragma unroll
+		for (int y = 0; y < 4; y++) {
+			const int i = 4 * ib + x, j = 4 * jb + y;
+			const double v = (j < a.n2) ? acc[x][y] : 0.0;
+			Rs[i * 68 + j] = v;
+			a.r12d[i * 64 + j] = v;
+			if (j < a.n2) a.r[(size_t)(64 + j) * a.ldr + i] = (float)v;
+		}
+	// original G22 into Gd (dense, upper triangle of the tile pairs)
+	__syncthreads();
+	for (int e = t; e < 10 * 256; e += 256) {
+		const int tile = e >> 8, reg = (e >> 6) & 3, l = e & 63;
+		int ti = 0, rem = tile;
+		while (rem >= 4 - ti) { rem -= 4 - ti; ti++; }
+		const int tj = ti + rem;
+		const int row = 16 * ti + 4 * (l >> 4) + reg, col = 16 * tj + (l & 15);
+		const double v = a.gsum[WIDE_G22 + e];
+		if (row <= col) { Gd[row * 68 + col] = v; Gd[col * 68 + row] = v; }
+	}
+	__syncthreads();
+	// G22'[x][y] = G22[x][y] - sum_i R12[i][x] R12[i][y]   for the 4 x 4 blocks on or above the diagonal
+	if (ib <= jb) {
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+#pragma unroll
+			for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
+#pragma unroll 4
+		for (int i = 0; i < 64; i++) {
+			double rx[4], ry[4];
+#pragma unroll
+			for (int x = 0; x < 4; x++) { rx[x] = Rs[i * 68 + 4 * ib + x]; ry[x] = Rs[i * 68 + 4 * jb + x]; }
+#pragma unroll
+			for (int x = 0; x < 4; x++)
+#pragma unroll
+				for (int y = 0; y < 4; y++) acc[x][y] = fma(rx[x], ry[y], acc[x][y]);
+		}
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+#pragma unroll
+			for (int y = 0; y < 4; y++) {
+				const int row = 4 * ib + x, col = 4 * jb + y;
+				const int ti = row >> 4, tj = col >> 4;
+				if (row <= col && tj < a.NT2) {
+					const double v = Gd[row * 68 + col] - acc[x][y];
+					const int tile = ti * a.NT2 - (ti * (ti - 1)) / 2 + (tj - ti);
+					a.g2[tile * 256 + (row & 3) * 64 + 16 * ((row & 15) >> 2) + (col & 15)] = v;
+					if (ti == tj)                        // a diagonal tile also holds the mirror position
+						a.g2[tile * 256 + (col & 3) * 64 + 16 * ((col & 15) >> 2) + (row & 15)] = v;
+				}
+			}
+	}
+}
+
+// zwide_kernel: one workgroup.  T = R12 Z22, Z12 = -Z11 T (fp64), the 128 x 128 fp32 Z (ld 128) for apply_wide_kernel, the verdict
+// over both blocks and the zeros below the diagonal of R.
+//   status out: [0] 0 accepted / 1 rejected, [1] smallest pivot ratio r_jj^2 / g_jj over all n columns, [2] S = ||D inverse(R)||_F^2 / n
+struct ZWideArgs {
+	const double* gsum;                  // original tiles (diagonals of G11 and G22 scale the verdict)
+	const double* z64_1; const double* z64_2; const double* r12d;
+	float* zw;                           // 128 x 128 out
+	float* r; size_t ldr; int n;         // zeros into rows 64.., columns < 64
+	const unsigned* st1; const unsigned* st2;            // verdict words of the two block factorisations
+	unsigned* status; unsigned* host_status;
+	const double* rows_dev; double rows; float scond_floor;
+};
+__global__ __launch_bounds__(256) void zwide_kernel(const ZWideArgs a) {
+	__shared__ double As[64 * 68];                       // R12: As[i * 68 + x]   then T: As[k * 68 + y]
+	__shared__ double Bs[64 * 68];                       // Z22: Bs[x * 68 + y]   then Z11 transposed: Bs[k * 68 + i] = Z11[i][k]
+	__shared__ double dg[128], red[8];
+	const int t = threadIdx.x;
+	const int n2 = a.n - 64;
+	const bool blocks_ok = (a.st1[0] == 0) && (a.st2[0] == 0);
+	if (!blocks_ok) {
+		if (t == 0) {
+			a.status[0] = 1u; a.status[1] = 0u; a.status[2] = 0u;
+			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); hs[0] = 1u; }
+		}
+		return;
+	}
+	for (int e = t; e < 64 * 64; e += 256) {
+		As[(e >> 6) * 68 + (e & 63)] = a.r12d[e];        // r12d[i * 64 + x]
+		const int xx = e & 63, y = e >> 6;               // z64_2[y * 64 + x] = Z22[x][y]
+		Bs[xx * 68 + y] = a.z64_2[e];
+	}
+	if (t < 128) {                                       // original diagonal: tile (d, d), row = col = 16 d + c -> reg = c & 3, lane = 16 (c >> 2) + c
+		const int blk = t >> 6, j = t & 63, d = j >> 4, cc = j & 15;
+		dg[t] = a.gsum[(blk ? WIDE_G22 : 0) + tri4(d, d) * 256 + (cc & 3) * 64 + 16 * (cc >> 2) + cc];
+	}
+	__syncthreads();
+	const int ib = t >> 4, jb = t & 15;
+	double acc[4][4];
+#pragma unroll
+	for (int x = 0; x < 4; x++)
+#pragma unroll
+		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
+	// T[i][y] = sum_{x <= y} R12[i][x] Z22[x][y]
+#pragma unroll 4
+	for (int x = 0; x <= 4 * jb + 3; x++) {
+		double ri[4], zy[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { ri[u] = As[(4 * ib + u) * 68 + x]; zy[u] = Bs[x * 68 + 4 * jb + u]; }
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+#pragma unroll
+			for (int v = 0; v < 4; v++) acc[u][v] = fma(ri[u], zy[v], acc[u][v]);
+	}
+	// verdict sums over the diagonal blocks while the operands are at hand: sum_j g_jj Z[j][K]^2 (thread-strided)
+	double s_acc = 0.0;
+	float ratio = 1.0f;
+	for (int e = t; e < 64 * 64; e += 256) {
+		const int j = e & 63, K = e >> 6;                // z64[K * 64 + j] = Z[j][K]
+		const double z1 = a.z64_1[e];
+		s_acc = fma(dg[j] * z1, z1, s_acc);
+		if (j == K) ratio = fminf(ratio, (float)(1.0 / (dg[j] * z1 * z1)));
+		if (K < n2) {
+			const double z2 = Bs[j * 68 + K];
+			s_acc = fma(dg[64 + j] * z2, z2, s_acc);
+			if (j == K) ratio = fminf(ratio, (float)(1.0 / (dg[64 + j] * z2 * z2)));
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+#pragma unroll
+		for (int v = 0; v < 4; v++) As[(4 * ib + u) * 68 + 4 * jb + v] = acc[u][v];     // T[k][y]
+	for (int e = t; e < 64 * 64; e += 256) {
+		const int i = e & 63, k = e >> 6;                // z64_1[k * 64 + i] = Z11[i][k]
+		Bs[k * 68 + i] = a.z64_1[e];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int x = 0; x < 4; x++)
+#pragma unroll
+		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
+	// Z12[i][y] = - sum_{k >= i} Z11[i][k] T[k][y]
+#pragma unroll 4
+	for (int k = 4 * ib; k < 64; k++) {
+		double zi[4], ty[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { zi[u] = Bs[k * 68 + 4 * ib + u]; ty[u] = As[k * 68 + 4 * jb + u]; }
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+#pragma unroll
+			for (int v = 0; v < 4; v++) acc[u][v] = fma(-zi[u], ty[v], acc[u][v]);
+	}
+	// the assembled Z (column-major, ld 128): [Z11 Z12; 0 Z22], zero padded
+	for (int e = t; e < 64 * 64; e += 256) {
+		const int i = e & 63, j = e >> 6;
+		a.zw[(size_t)j * 128 + i] = (float)a.z64_1[e];               // Z11[i][j] (zero below the diagonal and beyond n already)
+		a.zw[(size_t)j * 128 + 64 + i] = 0.0f;
+		a.zw[(size_t)(64 + j) * 128 + 64 + i] = (float)a.z64_2[e];   // Z22[i][j]
+	}
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+#pragma unroll
+		for (int v = 0; v < 4; v++) {
+			const int i = 4 * ib + u, y = 4 * jb + v;
+			const double z = (y < n2) ? acc[u][v] : 0.0;
+			a.zw[(size_t)(64 + y) * 128 + i] = (float)z;
+			s_acc = fma(dg[i] * z, z, s_acc);
+		}
+	for (int e = t; e < 64 * n2; e += 256) {             // R below the diagonal blocks: rows 64.., columns < 64
+		const int i = e % n2, j = e / n2;
+		a.r[(size_t)j * a.ldr + 64 + i] = 0.0f;
+	}
+	for (int o = 32; o > 0; o >>= 1) { s_acc += __shfl_xor(s_acc, o); ratio = fminf(ratio, __shfl_xor(ratio, o)); }
+	if ((t & 63) == 0) { red[t >> 6] = s_acc; red[4 + (t >> 6)] = (double)ratio; }
+	__syncthreads();
+	if (t == 0) {
+		const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
+		const float scond = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)a.n);
+		const float rmin = fminf(fminf((float)red[4], (float)red[5]), fminf((float)red[6], (float)red[7]));
+		const float max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
+		const unsigned s0 = (rmin > 0.03125f && scond <= max_scond) ? 0u : 1u;       // NaN compares false -> rejected
+		a.status[0] = s0;
+		a.status[1] = __builtin_bit_cast(unsigned, rmin);
+		a.status[2] = __builtin_bit_cast(unsigned, scond);
+		if (a.host_status) {
+			volatile unsigned* hs = a.host_status;
+			hs[1] = __builtin_bit_cast(unsigned, rmin);
+			hs[2] = __builtin_bit_cast(unsigned, scond);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+			hs[0] = s0;
+		}
+	}
+}
+
+}  // namespace tsqrmi
