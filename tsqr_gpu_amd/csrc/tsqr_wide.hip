@@ -231,21 +231,39 @@ struct SchurArgs {
 	const double* gsum; const double* z64_1; double* r12d; double* g2; float* r; size_t ldr; int n2; int NT2;
 	const unsigned* prev_status;
 };
+// (One workgroup: the time is the chain of dependent memory round trips, not the 2 x 64^3 flops.  So every global load is issued
+// up front, and the barriers wait for LDS only -- __syncthreads() would also wait for the stores in flight.)
 __global__ __launch_bounds__(256) void schur_kernel(const SchurArgs a) {
 	__shared__ double Zs[64 * 68];                       // Zs[k * 68 + i] = Z11[k][i]   (then R12: Rs[i * 68 + j])
 	__shared__ double Gd[64 * 68];                       // Gd[k * 68 + j] = G12[k][j]
+	__shared__ double G2[64 * 68];                       // original G22, dense (upper triangle of the tile pairs and its mirror)
 	if (a.prev_status && a.prev_status[0] != 0) return;
 	const int t = threadIdx.x;
-	for (int e = t; e < 64 * 64; e += 256) {
-		const int k = e & 63, i = e >> 6;                // z64_1[i * 64 + k] = Z11[k][i]
-		Zs[k * 68 + i] = a.z64_1[e];
-	}
-	for (int e = t; e < 16 * 256; e += 256) {
+	double zin[16], gin[16], g2in[10];
+#pragma unroll
+	for (int u = 0; u < 16; u++) zin[u] = a.z64_1[t + 256 * u];
+#pragma unroll
+	for (int u = 0; u < 16; u++) gin[u] = a.gsum[WIDE_G12 + t + 256 * u];
+#pragma unroll
+	for (int u = 0; u < 10; u++) g2in[u] = a.gsum[WIDE_G22 + t + 256 * u];
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int e = t + 256 * u;
+		Zs[(e & 63) * 68 + (e >> 6)] = zin[u];           // z64_1[i * 64 + k] = Z11[k][i]
 		const int tile = e >> 8, reg = (e >> 6) & 3, l = e & 63;
-		const int row = 16 * (tile >> 2) + 4 * (l >> 4) + reg, col = 16 * (tile & 3) + (l & 15);
-		Gd[row * 68 + col] = a.gsum[WIDE_G12 + e];
+		Gd[(16 * (tile >> 2) + 4 * (l >> 4) + reg) * 68 + 16 * (tile & 3) + (l & 15)] = gin[u];
 	}
-	__syncthreads();
+	{
+		int ti = 0, tj = 0;                              // tile u of the packed upper triangle (4 x 4 tiles)
+#pragma unroll
+		for (int u = 0; u < 10; u++) {
+			const int reg = t >> 6, l = t & 63;
+			const int row = 16 * ti + 4 * (l >> 4) + reg, col = 16 * tj + (l & 15);
+			if (row <= col) { G2[row * 68 + col] = g2in[u]; G2[col * 68 + row] = g2in[u]; }
+			if (++tj == 4) { ti++; tj = ti; }
+		}
+	}
+	lds_barrier();
 	const int ib = t >> 4, jb = t & 15;
 	double acc[4][4];
 #pragma unroll
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(256) void schur_kernel(const SchurArgs a) {
 #pragma unroll
 			for (int y = 0; y < 4; y++) acc[x][y] = fma(zi[x], gj[y], acc[x][y]);
 	}
-	__syncthreads();
+	lds_barrier();
 	double* Rs = Zs;
 #pragma unroll
 	for (int x = 0; x < 4; x++)
@@ -275,18 +293,7 @@ __global__ __launch_bounds__(256) void schur_kernel(const SchurArgs a) {
 			a.r12d[i * 64 + j] = v;
 			if (j < a.n2) a.r[(size_t)(64 + j) * a.ldr + i] = (float)v;
 		}
-	// original G22 into Gd (dense, upper triangle of the tile pairs)
-	__syncthreads();
-	for (int e = t; e < 10 * 256; e += 256) {
-		const int tile = e >> 8, reg = (e >> 6) & 3, l = e & 63;
-		int ti = 0, rem = tile;
-		while (rem >= 4 - ti) { rem -= 4 - ti; ti++; }
-		const int tj = ti + rem;
-		const int row = 16 * ti + 4 * (l >> 4) + reg, col = 16 * tj + (l & 15);
-		const double v = a.gsum[WIDE_G22 + e];
-		if (row <= col) { Gd[row * 68 + col] = v; Gd[col * 68 + row] = v; }
-	}
-	__syncthreads();
+	lds_barrier();
 	// G22'[x][y] = G22[x][y] - sum_i R12[i][x] R12[i][y]   for the 4 x 4 blocks on or above the diagonal
 	if (ib <= jb) {
 #pragma unroll
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256) void schur_kernel(const SchurArgs a) {
 				const int row = 4 * ib + x, col = 4 * jb + y;
 				const int ti = row >> 4, tj = col >> 4;
 				if (row <= col && tj < a.NT2) {
-					const double v = Gd[row * 68 + col] - acc[x][y];
+					const double v = G2[row * 68 + col] - acc[x][y];
 					const int tile = ti * a.NT2 - (ti * (ti - 1)) / 2 + (tj - ti);
 					a.g2[tile * 256 + (row & 3) * 64 + 16 * ((row & 15) >> 2) + (col & 15)] = v;
 					if (ti == tj)                        // a diagonal tile also holds the mirror position
@@ -334,7 +341,8 @@ struct ZWideArgs {
 };
 __global__ __launch_bounds__(256) void zwide_kernel(const ZWideArgs a) {
 	__shared__ double As[64 * 68];                       // R12: As[i * 68 + x]   then T: As[k * 68 + y]
-	__shared__ double Bs[64 * 68];                       // Z22: Bs[x * 68 + y]   then Z11 transposed: Bs[k * 68 + i] = Z11[i][k]
+	__shared__ double Bs[64 * 68];                       // Z22: Bs[x * 68 + y]
+	__shared__ double Cs[64 * 68];                       // Z11 by columns: Cs[k * 68 + i] = Z11[i][k]
 	__shared__ double dg[128], red[8];
 	const int t = threadIdx.x;
 	const int n2 = a.n - 64;
@@ -346,16 +354,28 @@ __global__ __launch_bounds__(256) void zwide_kernel(const ZWideArgs a) {
 		}
 		return;
 	}
-	for (int e = t; e < 64 * 64; e += 256) {
-		As[(e >> 6) * 68 + (e & 63)] = a.r12d[e];        // r12d[i * 64 + x]
-		const int xx = e & 63, y = e >> 6;               // z64_2[y * 64 + x] = Z22[x][y]
-		Bs[xx * 68 + y] = a.z64_2[e];
-	}
+	// every global load up front (one round trip), see schur_kernel
+	double rin[16], z2in[16], z1in[16];
+#pragma unroll
+	for (int u = 0; u < 16; u++) rin[u] = a.r12d[t + 256 * u];
+#pragma unroll
+	for (int u = 0; u < 16; u++) z2in[u] = a.z64_2[t + 256 * u];
+#pragma unroll
+	for (int u = 0; u < 16; u++) z1in[u] = a.z64_1[t + 256 * u];
+	double dgin = 0.0;
 	if (t < 128) {                                       // original diagonal: tile (d, d), row = col = 16 d + c -> reg = c & 3, lane = 16 (c >> 2) + c
 		const int blk = t >> 6, j = t & 63, d = j >> 4, cc = j & 15;
-		dg[t] = a.gsum[(blk ? WIDE_G22 : 0) + tri4(d, d) * 256 + (cc & 3) * 64 + 16 * (cc >> 2) + cc];
+		dgin = a.gsum[(blk ? WIDE_G22 : 0) + tri4(d, d) * 256 + (cc & 3) * 64 + 16 * (cc >> 2) + cc];
 	}
-	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int e = t + 256 * u;
+		As[(e >> 6) * 68 + (e & 63)] = rin[u];           // r12d[i * 64 + x]
+		Bs[(e & 63) * 68 + (e >> 6)] = z2in[u];          // z64_2[y * 64 + x] = Z22[x][y]
+		Cs[(e >> 6) * 68 + (e & 63)] = z1in[u];          // z64_1[k * 64 + i] = Z11[i][k]
+	}
+	if (t < 128) dg[t] = dgin;
+	lds_barrier();
 	const int ib = t >> 4, jb = t & 15;
 	double acc[4][4];
 #pragma unroll
@@ -373,30 +393,37 @@ __global__ __launch_bounds__(256) void zwide_kernel(const ZWideArgs a) {
 #pragma unroll
 			for (int v = 0; v < 4; v++) acc[u][v] = fma(ri[u], zy[v], acc[u][v]);
 	}
-	// verdict sums over the diagonal blocks while the operands are at hand: sum_j g_jj Z[j][K]^2 (thread-strided)
+	// verdict sums over the diagonal blocks: sum_j g_jj Z[j][K]^2 and the pivot ratios 1 / (g_KK Z[K][K]^2)
 	double s_acc = 0.0;
 	float ratio = 1.0f;
-	for (int e = t; e < 64 * 64; e += 256) {
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int e = t + 256 * u;
 		const int j = e & 63, K = e >> 6;                // z64[K * 64 + j] = Z[j][K]
-		const double z1 = a.z64_1[e];
+		const double z1 = z1in[u];
 		s_acc = fma(dg[j] * z1, z1, s_acc);
 		if (j == K) ratio = fminf(ratio, (float)(1.0 / (dg[j] * z1 * z1)));
 		if (K < n2) {
-			const double z2 = Bs[j * 68 + K];
+			const double z2 = z2in[u];
 			s_acc = fma(dg[64 + j] * z2, z2, s_acc);
 			if (j == K) ratio = fminf(ratio, (float)(1.0 / (dg[64 + j] * z2 * z2)));
 		}
 	}
-	__syncthreads();
+	// the diagonal blocks of the assembled Z (column-major, ld 128): [Z11 Z12; 0 Z22], zero padded
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int e = t + 256 * u;
+		const int i = e & 63, j = e >> 6;
+		a.zw[(size_t)j * 128 + i] = (float)z1in[u];                  // Z11[i][j] (zero below the diagonal and beyond n already)
+		a.zw[(size_t)j * 128 + 64 + i] = 0.0f;
+		a.zw[(size_t)(64 + j) * 128 + 64 + i] = (float)z2in[u];      // Z22[i][j]
+	}
+	lds_barrier();
 #pragma unroll
 	for (int u = 0; u < 4; u++)
 #pragma unroll
 		for (int v = 0; v < 4; v++) As[(4 * ib + u) * 68 + 4 * jb + v] = acc[u][v];     // T[k][y]
-	for (int e = t; e < 64 * 64; e += 256) {
-		const int i = e & 63, k = e >> 6;                // z64_1[k * 64 + i] = Z11[i][k]
-		Bs[k * 68 + i] = a.z64_1[e];
-	}
-	__syncthreads();
+	lds_barrier();
 #pragma unroll
 	for (int x = 0; x < 4; x++)
 #pragma unroll
@@ -406,18 +433,11 @@ __global__ __launch_bounds__(256) void zwide_kernel(const ZWideArgs a) {
 	for (int k = 4 * ib; k < 64; k++) {
 		double zi[4], ty[4];
 #pragma unroll
-		for (int u = 0; u < 4; u++) { zi[u] = Bs[k * 68 + 4 * ib + u]; ty[u] = As[k * 68 + 4 * jb + u]; }
+		for (int u = 0; u < 4; u++) { zi[u] = Cs[k * 68 + 4 * ib + u]; ty[u] = As[k * 68 + 4 * jb + u]; }
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 #pragma unroll
 			for (int v = 0; v < 4; v++) acc[u][v] = fma(-zi[u], ty[v], acc[u][v]);
-	}
-	// the assembled Z (column-major, ld 128): [Z11 Z12; 0 Z22], zero padded
-	for (int e = t; e < 64 * 64; e += 256) {
-		const int i = e & 63, j = e >> 6;
-		a.zw[(size_t)j * 128 + i] = (float)a.z64_1[e];               // Z11[i][j] (zero below the diagonal and beyond n already)
-		a.zw[(size_t)j * 128 + 64 + i] = 0.0f;
-		a.zw[(size_t)(64 + j) * 128 + 64 + i] = (float)a.z64_2[e];   // Z22[i][j]
 	}
 #pragma unroll
 	for (int u = 0; u < 4; u++)
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(256) void zwide_kernel(const ZWideArgs a) {
 	}
 	for (int o = 32; o > 0; o >>= 1) { s_acc += __shfl_xor(s_acc, o); ratio = fminf(ratio, __shfl_xor(ratio, o)); }
 	if ((t & 63) == 0) { red[t >> 6] = s_acc; red[4 + (t >> 6)] = (double)ratio; }
-	__syncthreads();
+	lds_barrier();
 	if (t == 0) {
 		const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
 		const float scond = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)a.n);
