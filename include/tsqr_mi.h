@@ -151,8 +151,12 @@ int tsqr_mi_profile_read(double* ms, long* launches, int max_classes);
  *                     The compute mode selects the MFMA engine of the apply pass (exact fp32 / bf16x3 split / single fp16 product).
  *   1 always Householder TSQR.   2 always fp64 Gram (no fallback).   3 always bf16-split Gram (no check; tests only).
  *   4 auto without the bf16-split level.
+ *   5 auto, but 64 < n <= 128 goes straight to the 64-column panel path (policy 0 first tries all n columns as ONE Cholesky-QR
+ *     panel at the bf16-split level: one pass for the 128 x 128 Gram matrix, one for Q; same acceptance rule; A stays intact when it
+ *     is accepted, and when it is rejected the panel path runs on the untouched input).
  * tsqr_mi_last_engine(): 0 Householder, 1 fp64 Gram, 2 Gram rejected -> Householder, 3 bf16-split Gram,
- * 4 Gram rejected -> shifted Cholesky QR (shifted fp64 Cholesky + one plain fp64 sweep in place). */
+ * 4 Gram rejected -> shifted Cholesky QR (shifted fp64 Cholesky + one plain fp64 sweep in place),
+ * 5 bf16-split Gram over all n <= 128 columns at once (one panel). */
 void tsqr_mi_set_policy(int policy);
 int tsqr_mi_last_engine(void);
 

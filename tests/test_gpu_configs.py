@@ -42,7 +42,8 @@ def test_c1_128x16_against_host_lapack(env):
 
 @pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
 def test_c3_2pow20_x_128(env, mode):
-    """C3: M=2^20, N=128 (two 64-wide panels coupled by block modified Gram-Schmidt on the matrix cores)."""
+    """C3: M=2^20, N=128 (auto policy: all 128 columns as one Cholesky-QR panel; tests/test_gpu_wide.py also runs the 64-column
+    panel path -- block modified Gram-Schmidt on the matrix cores -- on the same matrix)."""
     torch, bq, harness, oracle = env
     m, n = 1 << 20, 128
     g = torch.Generator(device="cuda"); g.manual_seed(3)

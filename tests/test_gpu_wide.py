@@ -1,0 +1,131 @@
+"""GPU tests of the one-panel path for 64 < n <= 128 (tsqr_gpu_amd/csrc/tsqr_wide.hip; plays the role of reference
+src/blockqr.cu:45-178 for two panels at once): all n columns as ONE Cholesky-QR panel -- a 128-column Gram pass, the Cholesky factor
+in two 64 x 64 blocks with a Schur complement, one apply pass -- against fp64 LAPACK, the reference restatement (oracle) and the
+64-column panel path (policy 5) on the same inputs.  Tolerances as tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RES_TOL, ORTH_TOL, PAR_TOL = 5e-7, 5e-6, 2e-5
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def run(bq, torch, a, mode, reorth, policy, lda_pad=0, ldq_pad=0):
+    m, n = a.shape
+    lda, ldq = m + lda_pad, m + ldq_pad
+    buf = np.zeros((n, lda), np.float32); buf[:, :m] = a.T
+    d_a = torch.from_numpy(buf).cuda()
+    d_q = torch.full((n, ldq), float("nan"), dtype=torch.float32, device="cuda")
+    d_r = torch.full((n, n), 7.0, dtype=torch.float32, device="cuda")          # R must be written in full
+    bf = bq.buffer(mode, reorth); bf.allocate(m, n)
+    bq.set_policy(policy)
+    try:
+        st = bq.qr(d_q, ldq, d_r, n, d_a, lda, m, n, bf)
+        eng = bq.last_engine()
+    finally:
+        bq.set_policy(0)
+    q_full = d_q.cpu().numpy()
+    if ldq_pad:
+        assert np.isnan(q_full[:, m:]).all(), "wrote outside the m x n block of Q"
+    a_after = d_a.cpu().numpy()[:, :m].T
+    return st, eng, q_full[:, :m].T.copy(), d_r.cpu().numpy().T.copy(), a_after
+
+
+@pytest.mark.parametrize("m,n", [(3000, 65), (5001, 80), (9000, 100), (70001, 113), (4096, 128), (65536, 128), (1000, 128)])
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+@pytest.mark.parametrize("reorth", [False, True])
+def test_one_panel_against_oracle_and_panel_path(bq, oracle, torch_cuda, m, n, mode, reorth):
+    md = bq.compute_mode[mode]
+    a = oracle.uniform_matrix(m, n, seed=23)
+    st, eng, q, r, a_after = run(bq, torch_cuda, a, md, reorth, 0, lda_pad=(5 if m % 2 else 0), ldq_pad=3)
+    assert st == 0 and eng == 5                                     # the one-panel path took it
+    if not reorth:
+        assert np.array_equal(a_after, a)                            # ... and left A alone (the panel path overwrites it)
+    assert np.isfinite(q).all() and np.isfinite(r).all()
+    assert np.abs(np.tril(r, -1)).max() == 0.0
+    assert oracle.residual(a, q, r) < RES_TOL
+    assert oracle.orthogonality_fro(q) < ORTH_TOL
+    # the 64-column panel path on the same input
+    st_p, eng_p, q_p, r_p, _ = run(bq, torch_cuda, a, md, reorth, 5)
+    assert st_p == 0 and eng_p == 3
+    qn, rn = oracle.sign_normalise(q, r)
+    qpn, rpn = oracle.sign_normalise(q_p, r_p)
+    assert np.abs(rn - rpn).max() / np.abs(rpn).max() < PAR_TOL
+    assert np.abs(qn - qpn).max() < PAR_TOL
+    # the reference restatement (parity unpinned: bands, not bits)
+    if m <= 10000:
+        st_o, q_o, r_o = oracle.qr(a, int(md), reorth)
+        assert st_o == 0
+        qon, ron = oracle.sign_normalise(q_o, np.triu(r_o))
+        assert np.abs(rn - ron).max() / np.abs(ron).max() < PAR_TOL
+        assert np.abs(qn - qon).max() < PAR_TOL
+    # fp64 LAPACK
+    q2, r2 = np.linalg.qr(a.astype(np.float64))
+    _, r2n = oracle.sign_normalise(q2, r2)
+    assert np.abs(rn - r2n).max() / np.abs(r2n).max() < 1e-5
+
+
+@pytest.mark.parametrize("cond,reorth", [(1e4, False), (1e4, True), (1e7, True)])
+def test_ill_conditioned_falls_back_to_the_panel_path(bq, oracle, torch_cuda, cond, reorth):
+    """the verdict over both blocks rejects, A is still intact, the panel path runs on it: bit-identical to policy 5"""
+    rng = np.random.Generator(np.random.MT19937(5))
+    m, n = 20000, 128
+    u, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    v, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    a = ((u * np.geomspace(1.0, 1.0 / cond, n)) @ v.T).astype(np.float32)
+    md = bq.compute_mode.fp32_tc_cor
+    st, eng, q, r, _ = run(bq, torch_cuda, a, md, reorth, 0)
+    st_p, eng_p, q_p, r_p, _ = run(bq, torch_cuda, a, md, reorth, 5)
+    assert st == 0 and st_p == 0 and eng != 5 and eng == eng_p
+    assert np.array_equal(r, r_p) and np.array_equal(q, q_p)
+    assert oracle.residual(a, q, r) < 1e-6
+    if reorth:
+        assert oracle.orthogonality_fro(q) < 2e-5
+
+
+def test_scaled_columns_and_few_rows(bq, oracle, torch_cuda):
+    """column scaling does not change the scaled conditioning S (accepted); with few rows the S bound is 4 and the panel path may take over"""
+    md = bq.compute_mode.fp32_tc_cor
+    a = oracle.uniform_matrix(30000, 128, seed=3) * np.geomspace(1e-6, 1e6, 128).astype(np.float32)
+    st, eng, q, r, _ = run(bq, torch_cuda, a, md, False, 0)
+    assert st == 0 and eng == 5
+    assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL
+    a = oracle.uniform_matrix(129, 128, seed=4)                      # barely tall: cond ~ 1e3
+    st, eng, q, r, _ = run(bq, torch_cuda, a, md, True, 0)
+    assert st == 0 and eng != 5
+    assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL
+
+
+def test_full_size_c3_both_paths(bq, oracle, torch_cuda):
+    """BASELINE config C3 (2^20 x 128) through both paths: size-independent properties + agreement of the two R factors"""
+    torch = torch_cuda
+    from tsqr_gpu_amd import harness
+    m, n = 1 << 20, 128
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    d_a = torch.rand(n, m, generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    keep = d_a.clone()
+    rs = {}
+    for policy in (0, 5):
+        bq.set_policy(policy)
+        try:
+            d_a.copy_(keep)
+            st, d_q, d_r = harness.qr(d_a, m, n, bq.compute_mode.fp32_tc_cor, False)
+            eng = bq.last_engine()
+        finally:
+            bq.set_policy(0)
+        assert st == 0 and eng == (5 if policy == 0 else 3)
+        assert harness.orthogonality_fro(d_q, m, n) < 2e-6
+        assert harness.residual(d_q, d_r, keep, m, n) < 5e-7
+        assert torch.tril(d_r.T, -1).abs().max().item() == 0.0
+        if policy == 0:
+            assert torch.equal(d_a, keep)
+        rs[policy] = d_r.cpu().numpy().T.astype(np.float64)
+    s0 = np.sign(np.diag(rs[0])); s5 = np.sign(np.diag(rs[5]))
+    assert np.abs(s0[:, None] * rs[0] - s5[:, None] * rs[5]).max() / np.abs(rs[5]).max() < 1e-6

@@ -247,7 +247,7 @@ def profile_read():
 
 POLICY_AUTO, POLICY_HOUSEHOLDER, POLICY_GRAM_F64, POLICY_GRAM_BF16, POLICY_AUTO_NO_BF16 = 0, 1, 2, 3, 4
 ENGINE_NAMES = {0: "householder_tsqr", 1: "gram_f64_cholesky", 2: "gram_rejected_then_householder", 3: "gram_bf16x3_cholesky",
-                4: "gram_rejected_then_shifted_cholesky_qr2"}
+                4: "gram_rejected_then_shifted_cholesky_qr2", 5: "gram_bf16x3_cholesky_one_panel_128"}
 
 
 def set_policy(policy):

@@ -1001,6 +1001,7 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 		if (rc) return rc;
 	}
 	t_last_engine = !use_gram ? 0 : (c.used_householder ? 2 : (c.used_shift ? 4 : (c.min_level == 2 ? 3 : (c.min_level == 1 ? 1 : 2))));
+	if (wide_done) t_last_engine = 5;                    // all n <= 128 columns as one Cholesky-QR panel (bf16-split Gram level)
 	prof_collect();
 	return TSQR_MI_SUCCESS;
 }
