@@ -199,8 +199,10 @@ def main():
         from tsqr_gpu_amd import dist as tdist
         eng = tdist.RowPartitionedQR(mode, m, n, comm=args.dist_comm)    # one C call per step; RCCL called from C on this stream
 
+        dcall = eng.bind(d_q, ld, d_r, d_a, ld, reorthogonalize=bool(args.reorth))   # arguments marshalled once here too
+
         def step():
-            st = eng.qr(d_q, ld, d_r, d_a, ld, reorthogonalize=bool(args.reorth))
+            st = dcall()
             assert st == 0, st                              # (blocking like the single-GPU call: complete on return)
 
     def barrier():

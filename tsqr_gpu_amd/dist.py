@@ -129,7 +129,6 @@ class HipBackend:
         self.gather = torch.empty(world * n * n, dtype=torch.float32, device="cuda")
         self.comm = comm                               # RcclComm or None
         self.coll = collectives or TorchCollectives()
-        self.last_engine = 0
         self._cb_error = None
         self._ar = _ALLREDUCE_CB(self._allreduce)
         self._ag = _ALLGATHER_CB(self._allgather)
@@ -161,6 +160,10 @@ class HipBackend:
             self._cb_error = e
             return 1
 
+    @property
+    def last_engine(self):
+        return bq.last_engine()                        # (per host thread: the engine of this thread's last call)
+
     def qr_dist(self, q, ldq, r, ldr, a, lda, m_local, reorth):
         st = torch.cuda.current_stream().cuda_stream   # the callbacks issue torch work on the current stream: it must be this one
         L = bq.lib()
@@ -177,8 +180,31 @@ class HipBackend:
                 raise self._cb_error
         if rc < 0:
             raise RuntimeError("tsqr_mi_qr_f32_dist failed: %s" % bq.last_error())
-        self.last_engine = bq.last_engine()
         return rc
+
+
+    def bind_dist(self, q, ldq, r, ldr, a, lda, m_local, reorth):
+        """qr_dist with every argument marshalled once (as blockqr.bind): a zero-argument callable = one C-ABI call per invocation."""
+        st = torch.cuda.current_stream()
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L = bq.lib()
+        head = (ci(int(self.mode)), ci(int(reorth)), vp(q.data_ptr()), sz(ldq), vp(r.data_ptr()), sz(ldr), vp(a.data_ptr()), sz(lda),
+                sz(m_local), sz(self.n), vp(self.wq.data_ptr()), vp(self.wr.data_ptr()), vp(self.gather.data_ptr()))
+        if self.comm is not None:
+            fn, args = L.tsqr_mi_qr_f32_dist, head + (self.comm.comm, ci(self.world), vp(st.cuda_stream))
+        else:
+            fn, args = L.tsqr_mi_qr_f32_dist_cb, head + (self._ar, self._ag, None, ci(self.world), vp(st.cuda_stream))
+
+        def call():
+            self._cb_error = None
+            rc = fn(*args)
+            if self._cb_error is not None:
+                raise self._cb_error
+            if rc < 0:
+                raise RuntimeError("tsqr_mi_qr_f32_dist failed: %s" % bq.last_error())
+            return rc
+        call._keep = (q, r, a, st, self)
+        return call
 
 
 class RowPartitionedQR:
@@ -216,6 +242,14 @@ class RowPartitionedQR:
         if self.n == 0 or m_local == 0:
             return bq.error_invalid_matrix_size
         return self.backend.qr_dist(q, ldq, r, self.n, a, lda, m_local, bool(reorthogonalize))
+
+    def bind(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None):
+        """The same call with its arguments marshalled once: returns a zero-argument callable (a C++ caller's loop body).  The
+        tensors and the current stream must stay alive and unchanged while it is in use."""
+        m_local = self.m_local if m_local is None else m_local
+        if hasattr(self.backend, "bind_dist") and self.n > 0 and m_local > 0:
+            return self.backend.bind_dist(q, ldq, r, self.n, a, lda, m_local, bool(reorthogonalize))
+        return lambda: self.qr(q, ldq, r, a, lda, reorthogonalize, m_local)
 
     @property
     def last_engine(self):
