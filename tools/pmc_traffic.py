@@ -5,8 +5,8 @@ prescribes for gfx950 (FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE counts 128-B req
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [round]"""
 import csv, glob, json, sys, collections
 
-CLASS = {"apply_wg_kernel": "apply", "gram_bf16_kernel": "gram", "gram_kernel": "gram"}
-ALG = {"apply": 8 * (1 << 20) * 64, "gram": 4 * (1 << 20) * 64}
+CLASS = {"apply_wg_kernel": "apply", "gram_bf16_kernel": "gram", "gram_kernel": "gram", "apply_wide_kernel": "apply_wide", "gram_wide_kernel": "gram_wide"}
+ALG = {"apply": 8 * (1 << 20) * 64, "gram": 4 * (1 << 20) * 64, "apply_wide": 8 * (1 << 20) * 128, "gram_wide": 4 * (1 << 20) * 128}
 
 
 def collect(d, counter):
