@@ -17,14 +17,9 @@
 #include <stdexcept>
 #include <string>
 #include "../tsqr_mi.h"
+#include "tsqr.hpp"                             // mtk::tsqr (the reference's blockqr.hpp includes its tsqr.hpp as well)
 
 namespace mtk {
-namespace tsqr {
-// reference src/tsqr.cu:39-44
-inline std::size_t get_batch_size_log2(const std::size_t m) { return tsqr_mi_batch_size_log2(m); }
-inline std::size_t get_batch_size(const std::size_t m) { return tsqr_mi_batch_size(m); }
-}  // namespace tsqr
-
 namespace qr {
 
 enum compute_mode {

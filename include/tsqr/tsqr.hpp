@@ -1,0 +1,132 @@
+// tsqr.hpp -- the mtk::tsqr surface a caller of the reference sees through blockqr.hpp (reference src/blockqr.hpp:7 includes
+// src/tsqr.hpp): compute_mode (src/tsqr.hpp:9-20), the batch-size rule (:22-23), the element-type traits (:25-39), the work-space
+// sizes (:42-46), buffer<mode> (:49-108) and tsqr16<mode> (:110-140) -- thin QR of one panel of at most 16 columns in the
+// reference; this engine takes any n <= 64 through the same entry.
+//
+// Header-only over the extern "C" ABI of libtsqr_mi.so.  The stream argument is a hipStream_t where the reference has a
+// cudaStream_t.  fp32 I/O modes only (fp32_notc, fp32_tc_cor, fp32_tc_nocor); the others throw std::runtime_error -- tsqr16 returns
+// void in the reference, so there is no status to report them through.
+#ifndef __TSQR_HPP__
+#define __TSQR_HPP__
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+#include "../tsqr_mi.h"
+
+namespace mtk {
+namespace tsqr {
+
+enum compute_mode {
+	fp16_notc,
+	fp16_tc_nocor,
+	fp32_notc,
+	fp32_tc_cor,
+	fp32_tc_nocor,
+	mixed_tc_cor_emu,
+	tf32_tc_cor,
+	tf32_tc_cor_emu,
+	tf32_tc_nocor,
+	tf32_tc_nocor_emu,
+};
+
+inline std::size_t get_batch_size_log2(const std::size_t m) { return tsqr_mi_batch_size_log2(m); }
+inline std::size_t get_batch_size(const std::size_t m) { return tsqr_mi_batch_size(m); }
+
+// every mode this engine implements works on float; the half-typed modes keep their names so that code mentioning them compiles
+template <compute_mode mode> struct get_working_q_type { using type = float; };
+template <compute_mode mode> struct get_working_r_type { using type = float; };
+template <compute_mode mode> struct get_io_type { using type = float; };
+
+inline std::size_t get_working_q_size(const std::size_t m, const std::size_t n) { return tsqr_mi_working_q_size(m, n); }
+inline std::size_t get_working_r_size(const std::size_t m, const std::size_t n) { return tsqr_mi_working_r_size(m, n); }
+inline std::size_t get_working_l_size(const std::size_t m) { return tsqr_mi_working_l_size(m); }
+
+namespace detail {
+enum class where { device, pinned_host };
+inline void* grab(where w, std::size_t bytes, const char* what) {
+	void* p = nullptr;
+	const hipError_t e = (w == where::device) ? hipMalloc(&p, bytes) : hipHostMalloc(&p, bytes);
+	if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+	return p;
+}
+template <class T> inline void drop(where w, T*& p) {
+	if (p) (void)((w == where::device) ? hipFree(p) : hipHostFree(p));
+	p = nullptr;
+}
+}  // namespace detail
+
+// work space of one panel factorisation: dwq, dwr, dl on the device (or all in pinned host memory: allocate_host), hl pinned
+template <mtk::tsqr::compute_mode mode>
+struct buffer {
+	typename get_working_q_type<mode>::type* dwq = nullptr;
+	typename get_working_r_type<mode>::type* dwr = nullptr;
+	unsigned* dl = nullptr;
+	unsigned* hl = nullptr;
+	std::size_t total_memory_size = 0;
+
+	buffer() = default;
+	buffer(const buffer&) = delete;
+	buffer& operator=(const buffer&) = delete;
+	~buffer() { destroy(); }
+
+	void allocate(const std::size_t m, const std::size_t n) { fill(detail::where::device, m, n); }
+	void allocate_host(const std::size_t m, const std::size_t n) { fill(detail::where::pinned_host, m, n); }
+	void destroy() { release(detail::where::device); }
+	void destroy_host() { release(detail::where::pinned_host); }
+	std::size_t get_device_memory_size() const { return total_memory_size; }
+
+private:
+	void fill(detail::where w, const std::size_t m, const std::size_t n) {
+		if (dwq || dwr || dl || hl) throw std::runtime_error("The buffer has been already allocated");
+		const std::size_t q_bytes = sizeof(*dwq) * get_working_q_size(m, n), r_bytes = sizeof(*dwr) * get_working_r_size(m, n),
+		                  l_bytes = sizeof(unsigned) * get_working_l_size(m);
+		dwq = static_cast<decltype(dwq)>(detail::grab(w, q_bytes, "mtk::tsqr::buffer dwq"));
+		dwr = static_cast<decltype(dwr)>(detail::grab(w, r_bytes, "mtk::tsqr::buffer dwr"));
+		dl = static_cast<unsigned*>(detail::grab(w, l_bytes, "mtk::tsqr::buffer dl"));
+		hl = static_cast<unsigned*>(detail::grab(detail::where::pinned_host, l_bytes, "mtk::tsqr::buffer hl"));
+		total_memory_size = q_bytes + r_bytes + l_bytes;
+	}
+	void release(detail::where w) {
+		detail::drop(w, dwq);
+		detail::drop(w, dwr);
+		detail::drop(w, dl);
+		detail::drop(detail::where::pinned_host, hl);
+	}
+};
+
+// Q (m x n, ldq), R (n x n, ldr) of the panel A (m x n, lda); column-major; blocking; A is not modified.
+template <mtk::tsqr::compute_mode mode>
+inline void tsqr16(
+		typename get_io_type<mode>::type* const q_ptr, const std::size_t ldq,
+		typename get_io_type<mode>::type* const r_ptr, const std::size_t ldr,
+		const typename get_io_type<mode>::type* const a_ptr, const std::size_t lda,
+		const std::size_t m, const std::size_t n,
+		typename get_working_q_type<mode>::type* const working_q_ptr,
+		typename get_working_r_type<mode>::type* const working_r_ptr,
+		unsigned* const d_working_l_ptr,
+		unsigned* const h_working_l_ptr,
+		hipStream_t const stream = nullptr) {
+	if (n > 64) throw std::runtime_error("mtk::tsqr::tsqr16: one panel has at most 64 columns (the reference's limit is 16)");
+	// (a panel of at most 64 columns is never written to by the engine: the const_cast only matches the C signature)
+	const int st = tsqr_mi_qr_f32(static_cast<int>(mode), 0, q_ptr, ldq, r_ptr, ldr, const_cast<float*>(a_ptr), lda, m, n,
+	                              working_q_ptr, working_r_ptr, nullptr, d_working_l_ptr, h_working_l_ptr, stream);
+	if (st < 0) throw std::runtime_error(std::string("mtk::tsqr::tsqr16: ") + tsqr_mi_last_error());
+	if (st != 0) throw std::runtime_error(st == 2 ? "mtk::tsqr::tsqr16: compute_mode not implemented on gfx950"
+	                                              : "mtk::tsqr::tsqr16: invalid matrix size");
+}
+
+template <mtk::tsqr::compute_mode mode>
+inline void tsqr16(
+		typename get_io_type<mode>::type* const q_ptr, const std::size_t ldq,
+		typename get_io_type<mode>::type* const r_ptr, const std::size_t ldr,
+		const typename get_io_type<mode>::type* const a_ptr, const std::size_t lda,
+		const std::size_t m, const std::size_t n,
+		mtk::tsqr::buffer<mode>& buffer,
+		hipStream_t const stream) {
+	mtk::tsqr::tsqr16<mode>(q_ptr, ldq, r_ptr, ldr, a_ptr, lda, m, n, buffer.dwq, buffer.dwr, buffer.dl, buffer.hl, stream);
+}
+
+}  // namespace tsqr
+}  // namespace mtk
+#endif /* end of include guard */

@@ -88,3 +88,4 @@ def test_cpp_header_compiles_and_links(bq):
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
     assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "sample_blockqr"))
+    assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "sample_tsqr16"))       # include/tsqr/tsqr.hpp: mtk::tsqr::tsqr16 / buffer

@@ -227,6 +227,13 @@ def test_cpp_sample_through_header(bq, torch_cuda):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0 and "SAMPLE OK" in out.stdout, out.stdout + out.stderr
+    # the lower-level entry mtk::tsqr::tsqr16 / mtk::tsqr::buffer (reference src/tsqr.hpp:49-140) through include/tsqr/tsqr.hpp
+    t16 = os.path.join(os.path.dirname(exe), "sample_tsqr16")
+    if not os.path.exists(t16):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "sample_tsqr16"])
+    out = subprocess.run([t16], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0 and "TSQR16 SAMPLE OK" in out.stdout, out.stdout + out.stderr
     # the reference's speed protocol from C++ (no Python in the loop): schema and sanity only, the numbers live in profiles/
     spd = os.path.join(os.path.dirname(exe), "speed_blockqr")
     if not os.path.exists(spd):
