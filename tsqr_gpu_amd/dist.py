@@ -101,8 +101,15 @@ class RcclComm:
         lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
         lib.ncclCommInitRank.restype = ctypes.c_int
         rc = lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank)
-        if rc != 0 or not comm.value:
-            raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+        good = (rc == 0 and bool(comm.value))
+        # second agreement: a communicator that exists on some ranks only would hang the first exchange -- all or nobody
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            if good:
+                lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+                lib.ncclCommDestroy(comm)
+            raise RuntimeError("ncclCommInitRank failed on at least one rank (%d here)" % rc)
         self.comm = comm
 
     def destroy(self):
