@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: gpu_ab_env.sh VAR   -- headline bench line with VAR=1 and VAR=0, twice each (A/B of an environment switch), then the C++ speed program
+# usage: gpu_ab_env.sh VAR   -- headline bench line with VAR=1 and VAR=0, twice each (A/B of one of the TSQR_MI_* environment switches), then the parity tests
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for v in 1 0; do
