@@ -53,7 +53,10 @@ def main():
                 dr = np.abs(sw[:, None] * rw - sp[:, None] * rp).max() / np.abs(rp).max()
                 tol_o = 5e-6 if mode != "fp32_tc_nocor" else 5e-3
                 tol_r = 5e-7 if mode != "fp32_tc_nocor" else 2e-3
-                good = w["res"] < tol_r and w["orth"] < tol_o and w["low"] == 0.0 and dr < 2e-5
+                if w["eng"] != 5:                                # rejected (few rows / ill conditioned): the panel path ran, bit for bit
+                    good = w["res"] < tol_r and w["low"] == 0.0 and dr == 0.0
+                else:
+                    good = w["res"] < tol_r and w["orth"] < tol_o and w["low"] == 0.0 and dr < (2e-5 if mode != "fp32_tc_nocor" else 1e-3)
                 ok &= good
                 print(f"{m}x{n} {mode} reorth={int(reorth)} wide: res {w['res']:.2e} orth {w['orth']:.2e} low {w['low']:.1e} eng {w['eng']} | "
                       f"panels: res {p['res']:.2e} orth {p['orth']:.2e} eng {p['eng']} | dR {dr:.2e} {'ok' if good else 'FAIL'}", flush=True)

@@ -852,7 +852,7 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 			if (K < n) {
 				Rf[K * 65 + j] = (float)rkj[u];
 				Zf[K * 65 + j] = (j <= K) ? (float)mkc[u] : 0.0f;                    // Z[j][K] = M[K][j]
-				Zd[K * 65 + j] = (j <= K) ? mkc[u] : 0.0;                            // (fp64 image for the two-block factorisation)
+				Zd[K * 65 + j] = (j <= K) ? mkc[u] : 0.0;                            // (fp64 image, read on by chol_wide_kernel)
 				if (j <= K) s_acc = fma(dgj * mkc[u], mkc[u], s_acc);                // sum of g_jj * Z[j][K]^2
 			}
 		}
@@ -879,8 +879,9 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 template <class LOADG>
 __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
-                                          float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double* __restrict__ z64 = nullptr) {
+                                          float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double** gs_out = nullptr) {
 	__shared__ double Gs[64 * 65];               // symmetric G (assembly); afterwards the fp64 image of Z: Gs[K * 65 + j] = Z[j][K]
+	if (gs_out) *gs_out = Gs;                    // (a caller in the same kernel may go on with that image: chol_wide_kernel)
 	__shared__ float Rf[64 * 65];                // R rows for the final store
 	__shared__ float Zf[64 * 65];                // rows of M = columns of Z for the final store (no global store inside the loop:
 	                                             // a workgroup barrier drains vmcnt, i.e. would wait for the store's round trip)
@@ -987,8 +988,6 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	// diagonal) from their LDS images, coalesced
 	for (int K = w; K < n; K += 4)
 		if (j < NP) z[(size_t)K * NP + j] = Zf[K * 65 + j];
-	if (z64)                                             // 64 x 64, column-major with ld 64: z64[K * 64 + j] = Z[j][K]; zero beyond n
-		for (int K = w; K < 64; K += 4) z64[K * 64 + j] = (K < n && j <= K) ? Gs[K * 65 + j] : 0.0;
 	{
 		const int i = t & 63;
 		if (i < n)
@@ -1011,8 +1010,6 @@ struct CholArgs {
 	int level;                           // 2 bf16-split Gram matrix (f32 accumulator layout; pivot ratio > 2^-5, S bound, column norms >= 2^-90 rows),
 	                                     // 1 fp64 Gram matrix (f64 accumulator layout; ratio > 2^-40), 3 shifted fp64 (ratio > 0: rejects only non-finite input)
 	float scond_floor;                   // bf16 level: S <= min(128, max(scond_floor, 0.12 sqrt(rows)))
-	double* z64;                         // optional: inverse(R) in fp64 (64 x 64 column-major) -- one diagonal block of the two-block
-	int no_scond_bound;                  // factorisation of 64 < n <= 128 columns, whose conditioning verdict is taken over both blocks
 };
 
 __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
@@ -1037,9 +1034,8 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 	} else {
 		shift = a.shift_coef * (rows * (double)a.n + (double)a.n * (double)(a.n + 1));
 	}
-	if (a.no_scond_bound) max_scond = INFINITY;
 	chol_body(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
-	          shift, min_diag, a.z64);
+	          shift, min_diag);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -183,10 +183,9 @@ GramPlan gram_plan(size_t m, size_t n) {
 }
 
 // extra work space of the one-panel path for 64 < n <= 128 (offsets in floats from WqLayout::wide; the doubles first, 16-byte aligned):
-// [summed tiles 36*256 + row count (+pad)][G22' 10*256][Z11 fp64 4096][Z22 fp64 4096][R12 fp64 4096] | [Z 128 x 128 fp32][Z22 fp32 4096]
+// [summed tiles 36*256 + row count (+pad)][G22' 10*256] | [Z 128 x 128 fp32][Z22 fp32 4096]
 constexpr size_t WIDE_G_DOUBLES = 36 * 256 + 8;
-constexpr size_t WIDE_OFF_G2 = 2 * WIDE_G_DOUBLES, WIDE_OFF_Z1 = WIDE_OFF_G2 + 2 * 2560, WIDE_OFF_Z2 = WIDE_OFF_Z1 + 2 * 4096,
-                 WIDE_OFF_R12 = WIDE_OFF_Z2 + 2 * 4096, WIDE_OFF_ZW = WIDE_OFF_R12 + 2 * 4096, WIDE_OFF_ZF2 = WIDE_OFF_ZW + 128 * 128,
+constexpr size_t WIDE_OFF_G2 = 2 * WIDE_G_DOUBLES, WIDE_OFF_ZW = WIDE_OFF_G2 + 2 * 2560, WIDE_OFF_ZF2 = WIDE_OFF_ZW + 128 * 128,
                  WIDE_FLOATS = WIDE_OFF_ZF2 + 4096;
 constexpr int WIDE_MAX_WGS = 256;                       // gram_wide_kernel: one eight-wave workgroup per CU
 inline size_t wide_part_floats(size_t m) { return (std::min<size_t>((m + 63) / 64, WIDE_MAX_WGS) + 1) * 36 * 256 * 2; }
@@ -791,12 +790,8 @@ int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, c
 	float* w = c.wq + c.L.wide;
 	double* gsum = reinterpret_cast<double*>(w);
 	double* g2 = reinterpret_cast<double*>(w + WIDE_OFF_G2);
-	double* z64_1 = reinterpret_cast<double*>(w + WIDE_OFF_Z1);
-	double* z64_2 = reinterpret_cast<double*>(w + WIDE_OFF_Z2);
-	double* r12d = reinterpret_cast<double*>(w + WIDE_OFF_R12);
 	float* zw = w + WIDE_OFF_ZW;
 	float* zf2 = w + WIDE_OFF_ZF2;
-	const int n2 = (int)(n - PW), NT2 = (n2 + 15) / 16;
 	unsigned* st1 = c.status_dev(2); unsigned* st2 = c.status_dev(3);
 	// full 64-row blocks of a 128-column matrix go to the fast form of the Gram kernel, whatever is left (ragged last rows, or the
 	// whole matrix when n < 128) to the general form; both write per-workgroup partials, one after the other
@@ -827,22 +822,14 @@ int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, c
 		ProfScope ps(KC_CHOL, c.st);
 		const int nelem = 36 * 256;
 		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, gsum, reinterpret_cast<const double*>(c.wr), wgs, nelem, (double)m);
-		tsqrmi::CholArgs ca{};
-		ca.r = r; ca.ldr = ldr; ca.z = c.wq + c.L.z; ca.status = st1; ca.gsum = gsum; ca.rows = (double)m;
-		ca.n = (int)PW; ca.NT = 4; ca.level = 2; ca.scond_floor = g_set.bf16_scond_floor; ca.z64 = z64_1; ca.no_scond_bound = 1;
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, ca);
-		tsqrmi::SchurArgs sa{};
-		sa.gsum = gsum; sa.z64_1 = z64_1; sa.r12d = r12d; sa.g2 = g2; sa.r = r; sa.ldr = ldr; sa.n2 = n2; sa.NT2 = NT2; sa.prev_status = st1;
-		hipLaunchKernelGGL(tsqrmi::schur_kernel, dim3(1), dim3(256), 0, c.st, sa);
-		ca.r = r + PW * ldr + PW; ca.z = zf2; ca.status = st2; ca.gsum = g2; ca.prev_status = st1;
-		ca.n = n2; ca.NT = NT2; ca.z64 = z64_2;
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, ca);
-		tsqrmi::ZWideArgs za{};
-		za.gsum = gsum; za.z64_1 = z64_1; za.z64_2 = z64_2; za.r12d = r12d; za.zw = zw; za.r = r; za.ldr = ldr; za.n = (int)n;
-		za.st1 = st1; za.st2 = st2; za.status = c.status_dev(c.slot);
-		za.host_status = c.hsig.dev ? c.hsig.dev + 4 * c.slot : nullptr;
-		za.rows = (double)m; za.scond_floor = g_set.bf16_scond_floor;
-		hipLaunchKernelGGL(tsqrmi::zwide_kernel, dim3(1), dim3(256), 0, c.st, za);
+		// chol(G11) -> Schur complement -> chol(G22') -> Z12 + verdict: one workgroup, one launch (chol_wide_kernel)
+		tsqrmi::CholWideArgs wa{};
+		wa.gsum = gsum; wa.g2 = g2; wa.r = r; wa.ldr = ldr; wa.n = (int)n; wa.zf1 = c.wq + c.L.z; wa.zf2 = zf2; wa.zw = zw;
+		wa.st1 = st1; wa.st2 = st2; wa.status = c.status_dev(c.slot);
+		wa.host_status = c.hsig.dev ? c.hsig.dev + 4 * c.slot : nullptr;
+		wa.prev_status = c.prev_slot >= 0 ? c.status_dev(c.prev_slot) : nullptr;
+		wa.rows = (double)m; wa.scond_floor = g_set.bf16_scond_floor;
+		hipLaunchKernelGGL(tsqrmi::chol_wide_kernel, dim3(1), dim3(256), 0, c.st, wa);
 	}
 	HIPCHK(hipGetLastError());
 	tsqrmi::ApplyArgs aa{};

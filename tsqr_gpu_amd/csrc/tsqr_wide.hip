@@ -6,11 +6,9 @@
 // with ONE read of A for G and one read + one write for Q (1.6 GB):
 //   gram_wide_kernel   : all 36 Gram tiles of a 64-row x 128-column block; the block is split ONCE into its three bf16 images in LDS
 //                        and every wave takes nine tile pairs (tile rows w and 7-w) with both MFMA operands read from LDS
-//   chol_kernel        : G11 -> R11, Z11 (fp32 + fp64)                              [existing kernel, block 1]
-//   schur_kernel       : R12 = Z11^T G12,  G22' = G22 - R12^T R12   (fp64)
-//   chol_kernel        : G22' -> R22, Z22                                           [block 2]
-//   zwide_kernel       : Z12 = -Z11 R12 Z22, the 128 x 128 Z for the apply pass, the verdict over BOTH blocks
-//                        (scaled conditioning S with the ORIGINAL diagonal of G, pivot ratios), zeros below the diagonal of R
+//   chol_wide_kernel   : one workgroup, one launch: chol(G11) -> R11, Z11 [chol_body]; R12 = Z11^T G12, G22' = G22 - R12^T R12;
+//                        chol(G22') -> R22, Z22 [chol_body]; Z12 = -Z11 R12 Z22, the 128 x 128 Z for the apply pass, the verdict
+//                        over BOTH blocks (scaled conditioning S with the ORIGINAL diagonal of G, pivot ratios)
 //   apply_wide_kernel  : Q = A * Z  (tsqr_kernels.hip)
 // The acceptance rule is the bf16-split Gram level's; a rejected factorisation leaves A untouched and the
 // caller falls back to the panel path.  Plays the role of reference src/blockqr.cu:45-178 for two panels at once.
@@ -221,219 +219,186 @@ __global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
 	}
 }
 
-// schur_kernel: one workgroup.  R12 = Z11^T G12 (64 x n2) and G22' = G22 - R12^T R12, both in fp64 with 4 x 4 register blocks.
-//   gsum : the summed tiles ([G11][G22][G12], f32 accumulator layout: row = 4 (lane >> 4) + reg, col = lane & 15)
-//   z64_1: inverse(R11), column-major ld 64 (chol_kernel)
-//   r12d : R12 out, r12d[i * 64 + j] (row i of R12 contiguous)
-//   g2   : G22' out in the accumulator order chol_kernel reads: the tiles (ti <= tj < NT2) packed row by row
-//   r    : the caller's R; R12 is written to its block (rows 0..63, columns 64..64+n2)
-struct SchurArgs {
-	const double* gsum; const double* z64_1; double* r12d; double* g2; float* r; size_t ldr; int n2; int NT2;
+// chol_wide_kernel: the whole two-block factorisation in ONE workgroup and one launch -- chol(G11), the Schur complement
+// R12 = Z11^T G12, G22' = G22 - R12^T R12, chol(G22'), Z12 = -Z11 R12 Z22, the 128 x 128 fp32 Z (ld 128) for apply_wide_kernel, the
+// verdict over BOTH blocks and the zeros below the diagonal blocks of R -- with the intermediate results handed on through LDS.
+// (As four launches -- chol, Schur, chol, Z12 -- the chain cost 24 + 16 + 24 + 21 us: a one-workgroup kernel pays a launch and at
+// least one dependent memory round trip each time; the 64^3 fp64 products themselves are ~4 us each.)
+//   gsum layout: [G11: 10 tiles][G22: 10 tiles][G12: 16 tiles], f32 accumulator layout (row = 4 (lane >> 4) + reg, col = lane & 15)
+//   status out : [0] 0 accepted / 1 rejected, [1] smallest pivot ratio r_jj^2 / g_jj over all n columns (ORIGINAL diagonal of G),
+//                [2] S = ||D inverse(R)||_F^2 / n
+struct PtrLoad { const double* p; __device__ double operator()(int e) const { return p[e]; } };
+struct CholWideArgs {
+	const double* gsum;                  // [G11 | G22 | G12] summed tiles (+ the row count behind them)
+	double* g2;                          // scratch: G22' in chol_body's tile order (2560 doubles)
+	float* r; size_t ldr; int n;         // R out (n x n)
+	float* zf1; float* zf2;              // fp32 Z11 / Z22 scratch (4096 floats each; chol_body writes them)
+	float* zw;                           // 128 x 128 Z out
+	unsigned* st1; unsigned* st2;        // verdict words of the two blocks (diagnostics)
+	unsigned* status; unsigned* host_status;
 	const unsigned* prev_status;
+	const double* rows_dev; double rows; float scond_floor;
 };
-// (One workgroup: the time is the chain of dependent memory round trips, not the 2 x 64^3 flops.  So every global load is issued
-// up front, and the barriers wait for LDS only -- __syncthreads() would also wait for the stores in flight.)
-__global__ __launch_bounds__(256) void schur_kernel(const SchurArgs a) {
-	__shared__ double Zs[64 * 68];                       // Zs[k * 68 + i] = Z11[k][i]   (then R12: Rs[i * 68 + j])
-	__shared__ double Gd[64 * 68];                       // Gd[k * 68 + j] = G12[k][j]
-	__shared__ double G2[64 * 68];                       // original G22, dense (upper triangle of the tile pairs and its mirror)
-	if (a.prev_status && a.prev_status[0] != 0) return;
+__global__ __launch_bounds__(256) void chol_wide_kernel(const CholWideArgs a) {
+	__shared__ double Gd[64 * 68];                       // G12: Gd[k * 68 + j]; later Z11 by columns: Cs[k * 68 + i] = Z11[i][k]
+	__shared__ double Rs[64 * 68];                       // R12: Rs[i * 68 + j]; later T = R12 Z22
+	__shared__ double dg[128], red[8];
+	__shared__ unsigned verdict[2];
 	const int t = threadIdx.x;
-	double zin[16], gin[16], g2in[10];
-#pragma unroll
-	for (int u = 0; u < 16; u++) zin[u] = a.z64_1[t + 256 * u];
+	const int n2 = a.n - 64, NT2 = (n2 + 15) / 16;
+	auto reject = [&]() {
+		if (t == 0) {
+			a.status[0] = 1u; a.status[1] = 0u; a.status[2] = 0u;
+			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); hs[0] = 1u; }
+		}
+	};
+	if (a.prev_status && a.prev_status[0] != 0) { reject(); return; }
+	const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
+	const double min_diag = rows * 0x1p-90;
+	// the inputs of the later phases are requested now: their latency hides behind the first factorisation
+	double gin[16], g2in[10], dgin = 0.0;
 #pragma unroll
 	for (int u = 0; u < 16; u++) gin[u] = a.gsum[WIDE_G12 + t + 256 * u];
 #pragma unroll
 	for (int u = 0; u < 10; u++) g2in[u] = a.gsum[WIDE_G22 + t + 256 * u];
+	if (t < 128) {                                       // original diagonal: tile (d, d), row = col = 16 d + c -> reg = c & 3, lane = 16 (c >> 2) + c
+		const int blk = t >> 6, j = t & 63, d = j >> 4, cc = j & 15;
+		dgin = a.gsum[(blk ? WIDE_G22 : 0) + tri4(d, d) * 256 + (cc & 3) * 64 + 16 * (cc >> 2) + cc];
+	}
+	// ---- block 1: R11, Z11 (fp64 image stays in LDS) ----
+	double* Zi = nullptr;                                // chol_body's LDS image of inverse(R): Zi[K * 65 + j] = Z[j][K]
+	chol_body(a.r, a.ldr, a.zf1, a.st1, nullptr, PtrLoad{a.gsum}, 64, 4, 1, 0.03125f, INFINITY, 0.0, min_diag, &Zi);
+	if (t == 0) verdict[0] = a.st1[0];                   // (written by this very thread inside chol_body)
+	if (t < 128) dg[t] = dgin;
 #pragma unroll
 	for (int u = 0; u < 16; u++) {
 		const int e = t + 256 * u;
-		Zs[(e & 63) * 68 + (e >> 6)] = zin[u];           // z64_1[i * 64 + k] = Z11[k][i]
 		const int tile = e >> 8, reg = (e >> 6) & 3, l = e & 63;
 		Gd[(16 * (tile >> 2) + 4 * (l >> 4) + reg) * 68 + 16 * (tile & 3) + (l & 15)] = gin[u];
 	}
-	{
-		int ti = 0, tj = 0;                              // tile u of the packed upper triangle (4 x 4 tiles)
-#pragma unroll
-		for (int u = 0; u < 10; u++) {
-			const int reg = t >> 6, l = t & 63;
-			const int row = 16 * ti + 4 * (l >> 4) + reg, col = 16 * tj + (l & 15);
-			if (row <= col) { G2[row * 68 + col] = g2in[u]; G2[col * 68 + row] = g2in[u]; }
-			if (++tj == 4) { ti++; tj = ti; }
-		}
-	}
-	lds_barrier();
+	__syncthreads();
+	if (verdict[0] != 0) { reject(); return; }
+	// ---- Schur complement: R12 = Z11^T G12, G22' = G22 - R12^T R12 ----
 	const int ib = t >> 4, jb = t & 15;
 	double acc[4][4];
 #pragma unroll
 	for (int x = 0; x < 4; x++)
 #pragma unroll
 		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
-	// R12[i][j] = sum_{k <= i} Z11[k][i] G12[k][j]
 #pragma unroll 4
-	for (int k = 0; k <= 4 * ib + 3; k++) {
+	for (int k = 0; k <= 4 * ib + 3; k++) {              // R12[i][j] = sum_{k <= i} Z11[k][i] G12[k][j];  Z11[k][i] = Zi[i * 65 + k]
 		double zi[4], gj[4];
 #pragma unroll
-		for (int x = 0; x < 4; x++) { zi[x] = Zs[k * 68 + 4 * ib + x]; gj[x] = Gd[k * 68 + 4 * jb + x]; }
+		for (int x = 0; x < 4; x++) { zi[x] = Zi[(4 * ib + x) * 65 + k]; gj[x] = Gd[k * 68 + 4 * jb + x]; }
 #pragma unroll
 		for (int x = 0; x < 4; x++)
 #pragma unroll
 			for (int y = 0; y < 4; y++) acc[x][y] = fma(zi[x], gj[y], acc[x][y]);
 	}
-	lds_barrier();
-	double* Rs = Zs;
 #pragma unroll
 	for (int x = 0; x < 4; x++)
 #pragma unroll
 		for (int y = 0; y < 4; y++) {
 			const int i = 4 * ib + x, j = 4 * jb + y;
-			const double v = (j < a.n2) ? acc[x][y] : 0.0;
+			const double v = (j < n2) ? acc[x][y] : 0.0;
 			Rs[i * 68 + j] = v;
-			a.r12d[i * 64 + j] = v;
-			if (j < a.n2) a.r[(size_t)(64 + j) * a.ldr + i] = (float)v;
+			if (j < n2) a.r[(size_t)(64 + j) * a.ldr + i] = (float)v;
 		}
-	lds_barrier();
-	// G22'[x][y] = G22[x][y] - sum_i R12[i][x] R12[i][y]   for the 4 x 4 blocks on or above the diagonal
-	if (ib <= jb) {
-#pragma unroll
-		for (int x = 0; x < 4; x++)
-#pragma unroll
-			for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
-#pragma unroll 4
-		for (int i = 0; i < 64; i++) {
-			double rx[4], ry[4];
-#pragma unroll
-			for (int x = 0; x < 4; x++) { rx[x] = Rs[i * 68 + 4 * ib + x]; ry[x] = Rs[i * 68 + 4 * jb + x]; }
+	lds_barrier();                                       // R12 complete; every wave is done with G12
+	double* Cs = Gd;
+	for (int e = t; e < 64 * 64; e += 256) Cs[(e >> 6) * 68 + (e & 63)] = Zi[(e >> 6) * 65 + (e & 63)];   // Z11 survives the second factorisation here
+	{
+		// -sum_i R12[i][x] R12[i][y] for this thread's 4 x 4 block, scattered to the tile layout through global scratch (2560 doubles)
+		if (ib <= jb) {
 #pragma unroll
 			for (int x = 0; x < 4; x++)
 #pragma unroll
-				for (int y = 0; y < 4; y++) acc[x][y] = fma(rx[x], ry[y], acc[x][y]);
-		}
+				for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
+#pragma unroll 4
+			for (int i = 0; i < 64; i++) {
+				double rx[4], ry[4];
 #pragma unroll
-		for (int x = 0; x < 4; x++)
+				for (int x = 0; x < 4; x++) { rx[x] = Rs[i * 68 + 4 * ib + x]; ry[x] = Rs[i * 68 + 4 * jb + x]; }
 #pragma unroll
-			for (int y = 0; y < 4; y++) {
-				const int row = 4 * ib + x, col = 4 * jb + y;
-				const int ti = row >> 4, tj = col >> 4;
-				if (row <= col && tj < a.NT2) {
-					const double v = G2[row * 68 + col] - acc[x][y];
-					const int tile = ti * a.NT2 - (ti * (ti - 1)) / 2 + (tj - ti);
-					a.g2[tile * 256 + (row & 3) * 64 + 16 * ((row & 15) >> 2) + (col & 15)] = v;
-					if (ti == tj)                        // a diagonal tile also holds the mirror position
-						a.g2[tile * 256 + (col & 3) * 64 + 16 * ((col & 15) >> 2) + (row & 15)] = v;
-				}
+				for (int x = 0; x < 4; x++)
+#pragma unroll
+					for (int y = 0; y < 4; y++) acc[x][y] = fma(rx[x], ry[y], acc[x][y]);
 			}
-	}
-}
-
-// zwide_kernel: one workgroup.  T = R12 Z22, Z12 = -Z11 T (fp64), the 128 x 128 fp32 Z (ld 128) for apply_wide_kernel, the verdict
-// over both blocks and the zeros below the diagonal of R.
-//   status out: [0] 0 accepted / 1 rejected, [1] smallest pivot ratio r_jj^2 / g_jj over all n columns, [2] S = ||D inverse(R)||_F^2 / n
-struct ZWideArgs {
-	const double* gsum;                  // original tiles (diagonals of G11 and G22 scale the verdict)
-	const double* z64_1; const double* z64_2; const double* r12d;
-	float* zw;                           // 128 x 128 out
-	float* r; size_t ldr; int n;         // zeros into rows 64.., columns < 64
-	const unsigned* st1; const unsigned* st2;            // verdict words of the two block factorisations
-	unsigned* status; unsigned* host_status;
-	const double* rows_dev; double rows; float scond_floor;
-};
-__global__ __launch_bounds__(256) void zwide_kernel(const ZWideArgs a) {
-	__shared__ double As[64 * 68];                       // R12: As[i * 68 + x]   then T: As[k * 68 + y]
-	__shared__ double Bs[64 * 68];                       // Z22: Bs[x * 68 + y]
-	__shared__ double Cs[64 * 68];                       // Z11 by columns: Cs[k * 68 + i] = Z11[i][k]
-	__shared__ double dg[128], red[8];
-	const int t = threadIdx.x;
-	const int n2 = a.n - 64;
-	const bool blocks_ok = (a.st1[0] == 0) && (a.st2[0] == 0);
-	if (!blocks_ok) {
-		if (t == 0) {
-			a.status[0] = 1u; a.status[1] = 0u; a.status[2] = 0u;
-			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); hs[0] = 1u; }
+#pragma unroll
+			for (int x = 0; x < 4; x++)
+#pragma unroll
+				for (int y = 0; y < 4; y++) {
+					const int row = 4 * ib + x, col = 4 * jb + y;
+					const int ti = row >> 4, tj = col >> 4;
+					if (row <= col) {
+						const int tile = tri4(ti, tj);
+						a.g2[tile * 256 + (row & 3) * 64 + 16 * ((row & 15) >> 2) + (col & 15)] = -acc[x][y];
+						if (ti == tj) a.g2[tile * 256 + (col & 3) * 64 + 16 * ((col & 15) >> 2) + (row & 15)] = -acc[x][y];
+					}
+				}
 		}
-		return;
+		__syncthreads();                                 // (global scratch written by other waves of this workgroup: full barrier)
+		// G22' = G22 + (-R12^T R12), repacked in place to chol_body's order (the tiles ti <= tj < NT2 row by row): thread t only
+		// touches position t of every tile and a packed index never exceeds the source index, so a target was read before
+		int ti = 0, tj = 0;
+#pragma unroll
+		for (int u = 0; u < 10; u++) {
+			const double v = g2in[u] + a.g2[u * 256 + t];
+			if (tj < NT2) a.g2[(ti * NT2 - (ti * (ti - 1)) / 2 + (tj - ti)) * 256 + t] = v;
+			if (++tj == 4) { ti++; tj = ti; }
+		}
 	}
-	// every global load up front (one round trip), see schur_kernel
-	double rin[16], z2in[16], z1in[16];
-#pragma unroll
-	for (int u = 0; u < 16; u++) rin[u] = a.r12d[t + 256 * u];
-#pragma unroll
-	for (int u = 0; u < 16; u++) z2in[u] = a.z64_2[t + 256 * u];
-#pragma unroll
-	for (int u = 0; u < 16; u++) z1in[u] = a.z64_1[t + 256 * u];
-	double dgin = 0.0;
-	if (t < 128) {                                       // original diagonal: tile (d, d), row = col = 16 d + c -> reg = c & 3, lane = 16 (c >> 2) + c
-		const int blk = t >> 6, j = t & 63, d = j >> 4, cc = j & 15;
-		dgin = a.gsum[(blk ? WIDE_G22 : 0) + tri4(d, d) * 256 + (cc & 3) * 64 + 16 * (cc >> 2) + cc];
-	}
-#pragma unroll
-	for (int u = 0; u < 16; u++) {
-		const int e = t + 256 * u;
-		As[(e >> 6) * 68 + (e & 63)] = rin[u];           // r12d[i * 64 + x]
-		Bs[(e & 63) * 68 + (e >> 6)] = z2in[u];          // z64_2[y * 64 + x] = Z22[x][y]
-		Cs[(e >> 6) * 68 + (e & 63)] = z1in[u];          // z64_1[k * 64 + i] = Z11[i][k]
-	}
-	if (t < 128) dg[t] = dgin;
-	lds_barrier();
-	const int ib = t >> 4, jb = t & 15;
-	double acc[4][4];
+	// ---- block 2: R22, Z22 ----
+	chol_body(a.r + 64 * a.ldr + 64, a.ldr, a.zf2, a.st2, nullptr, PtrLoad{a.g2}, n2, NT2, 1, 0.03125f, INFINITY, 0.0, min_diag, &Zi);
+	if (t == 0) verdict[1] = a.st2[0];
+	__syncthreads();
+	if (verdict[1] != 0) { reject(); return; }
+	// ---- Z12 = -Z11 (R12 Z22), the 128 x 128 Z, the verdict over both blocks ----
 #pragma unroll
 	for (int x = 0; x < 4; x++)
 #pragma unroll
 		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
-	// T[i][y] = sum_{x <= y} R12[i][x] Z22[x][y]
 #pragma unroll 4
-	for (int x = 0; x <= 4 * jb + 3; x++) {
+	for (int x = 0; x <= 4 * jb + 3; x++) {              // T[i][y] = sum_{x <= y} R12[i][x] Z22[x][y];  Z22[x][y] = Zi[y * 65 + x]
 		double ri[4], zy[4];
 #pragma unroll
-		for (int u = 0; u < 4; u++) { ri[u] = As[(4 * ib + u) * 68 + x]; zy[u] = Bs[x * 68 + 4 * jb + u]; }
+		for (int u = 0; u < 4; u++) { ri[u] = Rs[(4 * ib + u) * 68 + x]; zy[u] = Zi[(4 * jb + u) * 65 + x]; }
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 #pragma unroll
 			for (int v = 0; v < 4; v++) acc[u][v] = fma(ri[u], zy[v], acc[u][v]);
 	}
-	// verdict sums over the diagonal blocks: sum_j g_jj Z[j][K]^2 and the pivot ratios 1 / (g_KK Z[K][K]^2)
 	double s_acc = 0.0;
 	float ratio = 1.0f;
-#pragma unroll
-	for (int u = 0; u < 16; u++) {
-		const int e = t + 256 * u;
-		const int j = e & 63, K = e >> 6;                // z64[K * 64 + j] = Z[j][K]
-		const double z1 = z1in[u];
+	for (int e = t; e < 64 * 64; e += 256) {
+		const int j = e & 63, K = e >> 6;                // Z[j][K] of either block
+		const double z1 = Cs[K * 68 + j];
+		const double z2 = (K < n2) ? Zi[K * 65 + j] : 0.0;
 		s_acc = fma(dg[j] * z1, z1, s_acc);
-		if (j == K) ratio = fminf(ratio, (float)(1.0 / (dg[j] * z1 * z1)));
-		if (K < n2) {
-			const double z2 = z2in[u];
-			s_acc = fma(dg[64 + j] * z2, z2, s_acc);
-			if (j == K) ratio = fminf(ratio, (float)(1.0 / (dg[64 + j] * z2 * z2)));
+		s_acc = fma(dg[64 + j] * z2, z2, s_acc);
+		if (j == K) {
+			ratio = fminf(ratio, (float)(1.0 / (dg[j] * z1 * z1)));
+			if (K < n2) ratio = fminf(ratio, (float)(1.0 / (dg[64 + j] * z2 * z2)));
 		}
-	}
-	// the diagonal blocks of the assembled Z (column-major, ld 128): [Z11 Z12; 0 Z22], zero padded
-#pragma unroll
-	for (int u = 0; u < 16; u++) {
-		const int e = t + 256 * u;
-		const int i = e & 63, j = e >> 6;
-		a.zw[(size_t)j * 128 + i] = (float)z1in[u];                  // Z11[i][j] (zero below the diagonal and beyond n already)
-		a.zw[(size_t)j * 128 + 64 + i] = 0.0f;
-		a.zw[(size_t)(64 + j) * 128 + 64 + i] = (float)z2in[u];      // Z22[i][j]
+		a.zw[(size_t)K * 128 + j] = (float)z1;                       // Z11[j][K] (zero below the diagonal already)
+		a.zw[(size_t)K * 128 + 64 + j] = 0.0f;
+		a.zw[(size_t)(64 + K) * 128 + 64 + j] = (float)z2;           // Z22[j][K]
 	}
 	lds_barrier();
 #pragma unroll
 	for (int u = 0; u < 4; u++)
 #pragma unroll
-		for (int v = 0; v < 4; v++) As[(4 * ib + u) * 68 + 4 * jb + v] = acc[u][v];     // T[k][y]
+		for (int v = 0; v < 4; v++) Rs[(4 * ib + u) * 68 + 4 * jb + v] = acc[u][v];     // T[k][y]
 	lds_barrier();
 #pragma unroll
 	for (int x = 0; x < 4; x++)
 #pragma unroll
 		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
-	// Z12[i][y] = - sum_{k >= i} Z11[i][k] T[k][y]
 #pragma unroll 4
-	for (int k = 4 * ib; k < 64; k++) {
+	for (int k = 4 * ib; k < 64; k++) {                  // Z12[i][y] = - sum_{k >= i} Z11[i][k] T[k][y]
 		double zi[4], ty[4];
 #pragma unroll
-		for (int u = 0; u < 4; u++) { zi[u] = Cs[k * 68 + 4 * ib + u]; ty[u] = As[k * 68 + 4 * jb + u]; }
+		for (int u = 0; u < 4; u++) { zi[u] = Cs[k * 68 + 4 * ib + u]; ty[u] = Rs[k * 68 + 4 * jb + u]; }
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -456,7 +421,6 @@ __global__ __launch_bounds__(256) void zwide_kernel(const ZWideArgs a) {
 	if ((t & 63) == 0) { red[t >> 6] = s_acc; red[4 + (t >> 6)] = (double)ratio; }
 	lds_barrier();
 	if (t == 0) {
-		const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
 		const float scond = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)a.n);
 		const float rmin = fminf(fminf((float)red[4], (float)red[5]), fminf((float)red[6], (float)red[7]));
 		const float max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
