@@ -1257,6 +1257,12 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	constexpr int NI = NP / (NW * CPI);                   // load instructions per wave and block
 	constexpr int SL = ROWS / (16 * NW);                       // 16-row slabs per wave
 	constexpr int ZS = NP + 16;
+	// fp32-MFMA engine, triangular 128 x 128 Z: only the part on and right of the diagonal tiles is kept (row k holds the columns
+	// j >= 16 (k / 16)), 40 KiB instead of 72 -- two workgroups then share a CU.  The row stride of a 16-row group is its length padded
+	// to 16 or 48 mod 64 floats, so that the four rows a B operand touches (k = 4t + q) fall on different banks.
+	constexpr bool ZTRI = (ENGINE == 0 && NT == 8 && !UPD);
+	auto ztri_stride = [](int g) { return g == 0 ? 144 : (g <= 2 ? 112 : (g <= 4 ? 80 : (g <= 6 ? 48 : 16))); };
+	auto ztri_base = [&](int g) { int o = 0; for (int i = 0; i < g; i++) o += 16 * ztri_stride(i); return o; };
 	constexpr int KT = (NP + 31) / 32;
 	// blocks (kt, ct) of the MFMA-operand image of Z: for a triangular 64 x 64 Z the two blocks (1,0), (1,1) are zero and
 	// are not stored -- 18.4 KB instead of 24.6 KB, which lets three workgroups share a CU's LDS
@@ -1312,7 +1318,12 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 		float* Zs = reinterpret_cast<float*>(zbase);
 		for (int idx = threadIdx.x; idx < NP * NP; idx += 64 * NW) {
 			const int k = idx % NP, j = idx / NP;
-			Zs[k * ZS + j] = a.z[(size_t)j * NP + k];
+			if constexpr (ZTRI) {
+				const int g = k >> 4;
+				if (j >= 16 * g) Zs[ztri_base(g) + (k & 15) * ztri_stride(g) + (j - 16 * g)] = a.z[(size_t)j * NP + k];
+			} else {
+				Zs[k * ZS + j] = a.z[(size_t)j * NP + k];
+			}
 		}
 	} else if constexpr (ENGINE == 2) {
 		// Zh[kt][ct][lane][8] : B operand of v_mfma_f32_16x16x32_f16, one fp16 image (no correction terms)
@@ -1365,16 +1376,37 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 			for (int ct = 0; ct < NT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 			if constexpr (ENGINE == 0) {
 				const float* Zs = reinterpret_cast<const float*>(zbase);
-#pragma unroll
-				for (int t = 0; t < NP / 4; t++) {
+				// operands of k-step t+1 are requested before the products of k-step t are issued: an MFMA then never waits for its own
+				// LDS read (one read per product otherwise: 96 instead of 32 cycles per product)
+				auto fetch = [&](int t, float& av, float (&bv)[NT]) {
 					const int k = 4 * t + q;
-					const float av = As[k * RS + ((rb + c) ^ swz(k))];
+					av = As[k * RS + ((rb + c) ^ swz(k))];
 #pragma unroll
 					for (int ct = 0; ct < NT; ct++) {
+						bv[ct] = 0.0f;
 						if (UPD || 4 * t <= 16 * ct + 15) {
-							const float bv = Zs[k * ZS + 16 * ct + c];
-							acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ct], 0, 0, 0);
+							if constexpr (ZTRI) bv[ct] = Zs[ztri_base(t / 4) + (4 * (t % 4) + q) * ztri_stride(t / 4) + 16 * (ct - t / 4) + c];
+							else bv[ct] = Zs[k * ZS + 16 * ct + c];
 						}
+					}
+				};
+				float a0, a1, b0[NT], b1[NT];
+				fetch(0, a0, b0);
+				__builtin_amdgcn_sched_barrier(0);       // (keeps the scheduler from sinking the reads back next to their products)
+#pragma unroll
+				for (int t = 0; t < NP / 4; t += 2) {
+					if (t + 1 < NP / 4) fetch(t + 1, a1, b1);
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int ct = 0; ct < NT; ct++)
+						if (UPD || 4 * t <= 16 * ct + 15) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[ct], acc[ct], 0, 0, 0);
+					__builtin_amdgcn_sched_barrier(0);
+					if (t + 2 < NP / 4) fetch(t + 2, a0, b0);
+					__builtin_amdgcn_sched_barrier(0);
+					if (t + 1 < NP / 4) {
+#pragma unroll
+						for (int ct = 0; ct < NT; ct++)
+							if (UPD || 4 * (t + 1) <= 16 * ct + 15) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[ct], acc[ct], 0, 0, 0);
 					}
 				}
 			} else if constexpr (ENGINE == 2) {
@@ -1597,6 +1629,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int ENGINE>
 __global__ __launch_bounds__(512) void apply_wide_kernel(const ApplyArgs a) {
 	apply_wg_body<ENGINE, 8, false, 128, false, 8>(a);
+}
+// fp32-MFMA engine (fp32_notc): its product phase is four times longer per block, and with a single resident workgroup it does not
+// overlap the memory phases (320 us).  Four waves on 64-row blocks with the compact triangular Z: two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void apply_wide_f32_kernel(const ApplyArgs a) {
+	apply_wg_body<0, 8, false, 64, false, 4>(a);
 }
 
 // R <- R2 * R1 (n x n upper triangular, fp64 accumulation).  r1 is a packed copy (ld n) of the old R.

@@ -546,7 +546,7 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 		}
 		// persistent grid: as many workgroups as are resident on the 256 CUs at once (LDS / register bound: 2 or 3 per CU);
 		// measured: the fp32-MFMA engine is slower with three per CU (132 vs 112 us)
-		per_cu_cache[c.dev].store(std::min(nb, E == 0 ? 2 : (ROWS == 64 ? 4 : 3)));
+		per_cu_cache[c.dev].store(std::min(nb, ROWS == 64 ? 4 : (E == 0 ? 2 : 3)));
 		attr.done(c.dev);
 	}
 	const size_t nblk = cdiv(a.m, (size_t)ROWS);
@@ -570,6 +570,7 @@ template <int E, int NT, bool UPD> int launch_apply_any(Ctx& c, const tsqrmi::Ap
 	const int rows = g_set.apply_rows.load();
 	if (rows == 256) return launch_apply_wg<E, NT, UPD, 256>(c, a);
 	if constexpr (!UPD && E == 1) { if (rows == 64 || rows == 0) return launch_apply_wg<E, NT, UPD, 64>(c, a); }
+	if constexpr (!UPD && E == 0) { if (rows == 64) return launch_apply_wg<E, NT, UPD, 64>(c, a); }
 	return launch_apply_wg<E, NT, UPD, 128>(c, a);
 }
 template <int E> int dispatch_apply_nt(Ctx& c, int NT, const tsqrmi::ApplyArgs& a) {
@@ -773,17 +774,24 @@ int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq
 // has its block in LDS before it writes).  r receives the full n x n factor.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int E> int launch_apply_wide(Ctx& c, tsqrmi::ApplyArgs a) {
-	constexpr auto kernel = &tsqrmi::apply_wide_kernel<E>;
-	constexpr size_t lds = sizeof(float) * 128 * (128 + 4) + (E == 0 ? sizeof(float) * 128 * (128 + 16) : (size_t)(E == 2 ? 1 : 3) * 20 * 512 * 2);
+	// bf16x3 / fp16 engines: eight waves on 128-row blocks, one workgroup per CU; fp32-MFMA engine: four waves on 64-row blocks with
+	// the compact triangular Z (40 KiB), two workgroups per CU
+	constexpr bool F32 = (E == 0);
+	constexpr int ROWS = F32 ? 64 : 128, THREADS = F32 ? 256 : 512, PER_CU = F32 ? 2 : 1;
+	constexpr size_t lds = sizeof(float) * 128 * (ROWS + 4) + (F32 ? sizeof(float) * 10240 : (size_t)(E == 2 ? 1 : 3) * 20 * 512 * 2);
+	const void* kernel;
+	if constexpr (F32) kernel = reinterpret_cast<const void*>(&tsqrmi::apply_wide_f32_kernel);
+	else kernel = reinterpret_cast<const void*>(&tsqrmi::apply_wide_kernel<E>);
 	static DevOnce attr;
 	if (attr.need(c.dev)) {
-		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		attr.done(c.dev);
 	}
-	const size_t nblk = cdiv(a.m, (size_t)128);
+	const size_t nblk = cdiv(a.m, (size_t)ROWS);
 	a.nchunks = (int)nblk;
-	a.nwaves = (int)std::min<size_t>(nblk, 256);         // one workgroup of eight waves per CU
-	hipLaunchKernelGGL(kernel, dim3(a.nwaves), dim3(512), lds, c.st, a);
+	a.nwaves = (int)std::min<size_t>(nblk, (size_t)256 * PER_CU);
+	if constexpr (F32) hipLaunchKernelGGL(tsqrmi::apply_wide_f32_kernel, dim3(a.nwaves), dim3(THREADS), lds, c.st, a);
+	else hipLaunchKernelGGL(tsqrmi::apply_wide_kernel<E>, dim3(a.nwaves), dim3(THREADS), lds, c.st, a);
 	return 0;
 }
 int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, const float* a, size_t lda, size_t m, size_t n) {
