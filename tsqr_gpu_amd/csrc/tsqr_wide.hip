@@ -67,12 +67,22 @@ __device__ __forceinline__ void gram_wide_step(f32x4 (&acc)[9], const unsigned* 
 		rm[t] = *reinterpret_cast<const bf16x8*>(src + IMG);
 		rl[t] = *reinterpret_cast<const bf16x8*>(src + 2 * IMG);
 	});
+	// the images of column tile b+1 are requested before the products of column tile b are issued (scheduling barriers keep the
+	// compiler from sinking the reads back next to their first use): a product never waits for its own LDS read
+	bf16x8 bimg[2][3];
+	auto fetch_col = [&](int slot, int tile) {
+		const unsigned* src = base + 16 * tile * GW_CS;
+		bimg[slot][0] = *reinterpret_cast<const bf16x8*>(src);
+		bimg[slot][1] = *reinterpret_cast<const bf16x8*>(src + IMG);
+		bimg[slot][2] = *reinterpret_cast<const bf16x8*>(src + 2 * IMG);
+	};
+	fetch_col(0, R.col[0]);
+	__builtin_amdgcn_sched_barrier(0);
 	static_for<0, R.ncol>([&](auto bb) {
 		constexpr int b = decltype(bb)::value;
-		const unsigned* src = base + 16 * R.col[b] * GW_CS;
-		const bf16x8 bh = *reinterpret_cast<const bf16x8*>(src);
-		const bf16x8 bm = *reinterpret_cast<const bf16x8*>(src + IMG);
-		const bf16x8 bl = *reinterpret_cast<const bf16x8*>(src + 2 * IMG);
+		if constexpr (b + 1 < R.ncol) fetch_col((b + 1) & 1, R.col[b + 1]);
+		__builtin_amdgcn_sched_barrier(0);
+		const bf16x8 bh = bimg[b & 1][0], bm = bimg[b & 1][1], bl = bimg[b & 1][2];
 		// six of the nine partial products, smallest first: mm hl lh hm mh hh (as gram_bf16_kernel)
 		static_for<3, 9>([&](auto pp) {
 			constexpr int pass = decltype(pp)::value;
@@ -89,6 +99,7 @@ __device__ __forceinline__ void gram_wide_step(f32x4 (&acc)[9], const unsigned* 
 				}
 			});
 		});
+		__builtin_amdgcn_sched_barrier(0);
 	});
 }
 
