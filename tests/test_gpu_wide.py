@@ -38,7 +38,7 @@ def run(bq, torch, a, mode, reorth, policy, lda_pad=0, ldq_pad=0):
     return st, eng, q_full[:, :m].T.copy(), d_r.cpu().numpy().T.copy(), a_after
 
 
-@pytest.mark.parametrize("m,n", [(3000, 65), (5001, 80), (9000, 100), (70001, 113), (4096, 128), (65536, 128), (1000, 128)])
+@pytest.mark.parametrize("m,n", [(3000, 65), (5001, 80), (9000, 100), (70001, 113), (4096, 128), (65536, 128), (1000, 128), (262144, 128)])
 @pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
 @pytest.mark.parametrize("reorth", [False, True])
 def test_one_panel_against_oracle_and_panel_path(bq, oracle, torch_cuda, m, n, mode, reorth):
@@ -60,7 +60,7 @@ def test_one_panel_against_oracle_and_panel_path(bq, oracle, torch_cuda, m, n, m
     assert np.abs(rn - rpn).max() / np.abs(rpn).max() < PAR_TOL
     assert np.abs(qn - qpn).max() < PAR_TOL
     # the reference restatement (parity unpinned: bands, not bits)
-    if m <= 10000:
+    if m <= 10000 or (m == 262144 and mode == "fp32_tc_cor" and not reorth):      # (the large case once: ~15 s of host time)
         st_o, q_o, r_o = oracle.qr(a, int(md), reorth)
         assert st_o == 0
         qon, ron = oracle.sign_normalise(q_o, np.triu(r_o))
