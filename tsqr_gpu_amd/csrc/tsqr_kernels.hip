@@ -1694,14 +1694,6 @@ __global__ void host_flag_kernel(unsigned* __restrict__ host_flag, unsigned seq)
 	*reinterpret_cast<volatile unsigned*>(host_flag) = seq;
 }
 
-// the same signal carrying the three status words of a Cholesky kernel along (staged API: the caller supplied no pinned words)
-__global__ void host_status_flag_kernel(unsigned* __restrict__ host, const unsigned* __restrict__ status, unsigned seq) {
-	volatile unsigned* h = host;
-	h[0] = status[0]; h[1] = status[1]; h[2] = status[2];
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope: the host must never see seq before the status words
-	h[3] = seq;
-}
-
 __global__ __launch_bounds__(256) void copy2d_kernel(float* __restrict__ dst, size_t ldd, const float* __restrict__ src, size_t lds,
                                                      int rows, int cols) {
 	const size_t total = (size_t)rows * cols;
