@@ -555,3 +555,25 @@ extern "C" float tsqr_selftest_mfma_f64_rate(double* out, int wgs, int iters) {
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	return ms;
 }
+
+// ---- LDS bank behaviour of ds_read_b128: lane l = 16 q + c reads 16 bytes at dword (A c + B q); run under
+// rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS (tools/lds_pattern.py): which operand layouts are conflict free ----
+__global__ __launch_bounds__(256) void lds_b128_pattern_kernel(float* out, int A, int B, int iters) {
+	__shared__ __attribute__((aligned(16))) unsigned buf[16384];
+	for (int i = threadIdx.x; i < 16384; i += 256) buf[i] = i;
+	__syncthreads();
+	const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+	const unsigned* p = &buf[(A * c + B * q) & 16380];
+	unsigned acc = 0;
+	for (int i = 0; i < iters; i++) {
+		typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+		u32x4_t v;
+		asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)(p + ((i & 7) * 1024))) : "memory");
+		acc += v[0] ^ v[1] ^ v[2] ^ v[3];
+	}
+	if (acc == 0x12345678u) out[0] = 1.0f;
+}
+extern "C" int tsqr_selftest_lds_pattern(float* out, int A, int B, int iters) {
+	hipLaunchKernelGGL(lds_b128_pattern_kernel, dim3(256), dim3(256), 0, 0, out, A, B, iters);
+	return (int)hipDeviceSynchronize();
+}

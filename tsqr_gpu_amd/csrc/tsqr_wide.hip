@@ -29,7 +29,10 @@ __host__ __device__ constexpr int wide_tile(int ti, int tj) {
 }
 constexpr int WIDE_TILES = 36;
 constexpr int WIDE_G22 = 10 * 256, WIDE_G12 = 20 * 256;   // offsets (doubles) into the summed array
-constexpr int GW_CS = 36;                                // column stride of a bf16 image in dwords: 64 rows (32 dwords) + 4 of padding
+// Column stride of a bf16 image in dwords: 64 rows (32 dwords) + 8 of padding.  Measured with tools/lds_pattern.py (lane (c, q)
+// reads 16 bytes at dword A c + 4 q): ds_read_b128 is free of bank conflicts for A = 40 but not for A = 36, 44, 52, 68 ... -- the
+// sixteen lanes of a pass must agree in address bit 4 (or be pairwise contiguous); A = 36 gave SQ_LDS_BANK_CONFLICT = 8.3 M per launch.
+constexpr int GW_CS = 40;
 
 // Work split of the 36 tile pairs over four wave roles, nine pairs each, chosen so that a role touches few distinct column tiles
 // (every tile costs three 16-byte LDS reads per lane and K-step: 63 tile reads for all four roles instead of 102 with a row-wise
