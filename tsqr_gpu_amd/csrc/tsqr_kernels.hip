@@ -771,14 +771,20 @@ __global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ 
 	const int el = blockIdx.x * 16 + e;
 	double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 	if (el < nelem) {
-		int b = s;
-		for (; b + 48 < nparts; b += 64) {
-			s0 += part_load(&part[(size_t)b * nelem + el]);
-			s1 += part_load(&part[(size_t)(b + 16) * nelem + el]);
-			s2 += part_load(&part[(size_t)(b + 32) * nelem + el]);
-			s3 += part_load(&part[(size_t)(b + 48) * nelem + el]);
+		// the first 512 partials of this thread's stride: 32 loads issued back to back (one memory round trip instead of eight),
+		// then summed in the fixed order s_k += partial(s + 16 (4 i + k)), i ascending
+		double v[32];
+#pragma unroll
+		for (int u = 0; u < 32; u++) {
+			const int b = s + 16 * u;                        // (unconditional loads from a clamped index: no control flow between them)
+			v[u] = part_load(&part[(size_t)min(b, nparts - 1) * nelem + el]);
 		}
-		for (; b < nparts; b += 16) s0 += part_load(&part[(size_t)b * nelem + el]);
+#pragma unroll
+		for (int u = 0; u < 32; u++)
+			if (s + 16 * u >= nparts) v[u] = 0.0;
+#pragma unroll
+		for (int i = 0; i < 8; i++) { s0 += v[4 * i]; s1 += v[4 * i + 1]; s2 += v[4 * i + 2]; s3 += v[4 * i + 3]; }
+		for (int b = s + 512; b < nparts; b += 16) s0 += part_load(&part[(size_t)b * nelem + el]);
 	}
 	red[s][e] = (s0 + s1) + (s2 + s3);
 	__syncthreads();
