@@ -1342,17 +1342,28 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 		}
 	} else {
 		unsigned short* Zb = reinterpret_cast<unsigned short*>(zbase);
-		for (int idx = threadIdx.x; idx < NB * 64 * 8; idx += 64 * NW) {
+		// every load of a thread first (unconditional, from a clamped index: one L2 round trip for the whole staging instead of one
+		// per element -- all workgroups stage Z at the same moment, on the critical path of the pass), then the splits
+		constexpr int ZE = (NB * 64 * 8) / (64 * NW);
+		static_assert((NB * 64 * 8) % (64 * NW) == 0, "Z image elements divide evenly over the workgroup");
+		float zv[ZE];
+#pragma unroll
+		for (int u = 0; u < ZE; u++) {
+			const int idx = threadIdx.x + u * 64 * NW;
 			const int jj = idx & 7, l = (idx >> 3) & 63, b = idx >> 9;
 			const int kt = zblk_kt(b), ct = COMPACT ? b - (kt * NT - kt * (kt - 1)) + 2 * kt : b % NT;
 			const int k = 32 * kt + 8 * (l >> 4) + jj, j = 16 * ct + (l & 15);
-			const float v = (k < NP) ? a.z[(size_t)j * NP + k] : 0.0f;
+			zv[u] = a.z[(size_t)j * NP + min(k, NP - 1)];
+			if (k >= NP) zv[u] = 0.0f;
+		}
+#pragma unroll
+		for (int u = 0; u < ZE; u++) {
+			const int idx = threadIdx.x + u * 64 * NW;
 			unsigned h, m, lo;
-			split3(v, h, m, lo);
-			const int o = (b * 64 + l) * 8 + jj;
-			Zb[0 * NB * 512 + o] = (unsigned short)h;
-			Zb[1 * NB * 512 + o] = (unsigned short)m;
-			Zb[2 * NB * 512 + o] = (unsigned short)lo;
+			split3(zv[u], h, m, lo);
+			Zb[0 * NB * 512 + idx] = (unsigned short)h;      // o = (b * 64 + l) * 8 + jj = idx
+			Zb[1 * NB * 512 + idx] = (unsigned short)m;
+			Zb[2 * NB * 512 + idx] = (unsigned short)lo;
 		}
 	}
 
