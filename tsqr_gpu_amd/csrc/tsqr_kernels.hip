@@ -1322,24 +1322,40 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 
 	if constexpr (ENGINE == 0) {
 		float* Zs = reinterpret_cast<float*>(zbase);
-		for (int idx = threadIdx.x; idx < NP * NP; idx += 64 * NW) {
+		// (loads first, all in flight, then the LDS writes: see the bf16 engine below)
+		constexpr int ZE0 = (NP * NP) / (64 * NW);
+		static_assert((NP * NP) % (64 * NW) == 0, "Z elements divide evenly over the workgroup");
+		float zv0[ZE0];
+#pragma unroll
+		for (int u = 0; u < ZE0; u++) zv0[u] = a.z[threadIdx.x + u * 64 * NW];          // idx = j * NP + k: straight copy order
+#pragma unroll
+		for (int u = 0; u < ZE0; u++) {
+			const int idx = threadIdx.x + u * 64 * NW;
 			const int k = idx % NP, j = idx / NP;
 			if constexpr (ZTRI) {
 				const int g = k >> 4;
-				if (j >= 16 * g) Zs[ztri_base(g) + (k & 15) * ztri_stride(g) + (j - 16 * g)] = a.z[(size_t)j * NP + k];
+				if (j >= 16 * g) Zs[ztri_base(g) + (k & 15) * ztri_stride(g) + (j - 16 * g)] = zv0[u];
 			} else {
-				Zs[k * ZS + j] = a.z[(size_t)j * NP + k];
+				Zs[k * ZS + j] = zv0[u];
 			}
 		}
 	} else if constexpr (ENGINE == 2) {
 		// Zh[kt][ct][lane][8] : B operand of v_mfma_f32_16x16x32_f16, one fp16 image (no correction terms)
 		_Float16* Zh = reinterpret_cast<_Float16*>(zbase);
-		for (int idx = threadIdx.x; idx < NB * 64 * 8; idx += 64 * NW) {
+		constexpr int ZE2 = (NB * 64 * 8) / (64 * NW);
+		static_assert((NB * 64 * 8) % (64 * NW) == 0, "Z image elements divide evenly over the workgroup");
+		float zv2[ZE2];
+#pragma unroll
+		for (int u = 0; u < ZE2; u++) {                      // (loads first, all in flight: see the bf16 engine below)
+			const int idx = threadIdx.x + u * 64 * NW;
 			const int jj = idx & 7, l = (idx >> 3) & 63, b = idx >> 9;
 			const int kt = zblk_kt(b), ct = COMPACT ? b - (kt * NT - kt * (kt - 1)) + 2 * kt : b % NT;
 			const int k = 32 * kt + 8 * (l >> 4) + jj, j = 16 * ct + (l & 15);
-			Zh[(b * 64 + l) * 8 + jj] = (_Float16)((k < NP) ? a.z[(size_t)j * NP + k] : 0.0f);
+			zv2[u] = a.z[(size_t)j * NP + min(k, NP - 1)];
+			if (k >= NP) zv2[u] = 0.0f;
 		}
+#pragma unroll
+		for (int u = 0; u < ZE2; u++) Zh[threadIdx.x + u * 64 * NW] = (_Float16)zv2[u];
 	} else {
 		unsigned short* Zb = reinterpret_cast<unsigned short*>(zbase);
 		// every load of a thread first (unconditional, from a clamped index: one L2 round trip for the whole staging instead of one
