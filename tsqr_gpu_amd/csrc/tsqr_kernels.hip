@@ -1279,7 +1279,6 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* As = reinterpret_cast<float*>(smem);
 	char* zbase = smem + sizeof(float) * NP * RS;
-	if (a.skip_status && a.skip_status[0] != 0) return;  // uniform over the grid
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	const int c = lane & 15, q = lane >> 4;
@@ -1319,6 +1318,9 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	int bi = blockIdx.x;
 	if (bi < nblk) load_block(v, a.a, a.lda, a.n, blk(bi));
 	if constexpr (DEEP) { if (bi + nwg < nblk) load_block(v2, a.a, a.lda, a.n, blk(bi + nwg)); }
+	// (the verdict word is looked at only now: its round trip runs under the loads just issued; a skipped launch has merely
+	// requested a block or two of an input that is valid either way)
+	if (a.skip_status && a.skip_status[0] != 0) return;  // uniform over the grid
 
 	if constexpr (ENGINE == 0) {
 		float* Zs = reinterpret_cast<float*>(zbase);
