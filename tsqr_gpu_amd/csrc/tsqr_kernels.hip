@@ -112,11 +112,15 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
 	return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+	// (the two subtractions of a stage are one packed fp32 operation, v_pk_add_f32)
 	h = cvt_pk_bf16(a, b);
-	const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
-	m = cvt_pk_bf16(ra, rb);
-	const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
-	l = cvt_pk_bf16(sa, sb);
+	const f32x2_t x = {a, b};
+	const f32x2_t hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+	const f32x2_t r = x - hf;
+	m = cvt_pk_bf16(r[0], r[1]);
+	const f32x2_t mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+	const f32x2_t t = r - mf;
+	l = cvt_pk_bf16(t[0], t[1]);
 }
 
 // 3-way bf16 split of NPAIR independent pairs, written stage by stage (scheduling barriers in between) so that the
