@@ -1,4 +1,4 @@
-"""Two processes, ONE GPU, gloo: the row-partitioned driver with the PRODUCT engine (tsqr_mi_qr_f32_dist_cb: the C ladder calling
+"""Two (and four) processes, ONE GPU, gloo: the row-partitioned driver with the PRODUCT engine (tsqr_mi_qr_f32_dist_cb: the C ladder calling
 back into torch.distributed for its two exchanges).  Checks the global factorisation against fp64 LAPACK and the reference
 restatement (oracle), unequal block heights, the Householder all-gather branch (policy 1, incl. blocks shorter than the panel),
 reorthogonalisation and the escalation of an ill-conditioned input -- i.e. that every rank takes the same branch and ends with
@@ -65,7 +65,8 @@ def _run(heights, n, mode="fp32_tc_cor", reorth=False, policy=0, cond=1.0):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, heights, n, mode, reorth, policy, cond, out)) for r in range(2)]
+    world = len(heights)                                      # (at most 4 here: the GPU box allows 6 processes on its card)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, heights, n, mode, reorth, policy, cond, out)) for r in range(world)]
     for p in procs:
         p.start()
     res = out.get(timeout=300)
@@ -112,6 +113,15 @@ def test_two_ranks_householder_all_gather(oracle, reorth):
 def test_two_ranks_householder_blocks_shorter_than_the_panel(oracle):
     """m_local < n on both ranks: the gathered stack and its fold scratch need the *_size_dist work buffers"""
     res = _run((100, 60), 48, policy=1)
+    _check(res, oracle)
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+def test_four_ranks_unequal_blocks(oracle, policy):
+    """four processes on one GPU: the Gram all-reduce (policy 0) and the Householder all-gather of four R factors restacked to a
+    256 x 64 matrix (policy 1), block heights from 1 row to 30000"""
+    res = _run((30000, 1, 7777, 12345), 64, policy=policy)
+    assert res["engines"][0] == (3 if policy == 0 else 0)
     _check(res, oracle)
 
 
