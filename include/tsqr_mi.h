@@ -104,7 +104,8 @@ int tsqr_mi_apply_z_f32(int mode, float* q, size_t ldq, const float* a, size_t l
 int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t n, void* wq, void* stream);
 
 /* Row-partitioned TSQR (the reference has no multi-GPU path): one call per rank, every rank passes its own
- * row block (m_local may differ between ranks), r is bitwise identical on all ranks on return, n <= 64.  It is the SAME ladder as
+ * row block (m_local may differ between ranks, 1 <= m_local on every rank -- a rank that returns 1 for an empty block would leave
+ * the others waiting in their exchange; m_local < n is fine), r is bitwise identical on all ranks on return, n <= 64.  It is the SAME ladder as
  * tsqr_mi_qr_f32 with two exchange hooks switched on, all enqueued on `stream` with no host wait before the end of the call:
  *   Gram levels:        all-reduce (sum) of the Gram tiles + the local row count: <= 2561 doubles.  Every rank then factors the
  *                       same matrix with thresholds from the same (global) row count, so the accept / reject decisions agree on
@@ -113,7 +114,7 @@ int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t 
  * Work buffers: tsqr_mi_working_{q,r}_size_dist(m_local, n, nranks) elements; gather_buf: nranks*n*n floats.
  * tsqr_mi_qr_f32_dist: RCCL on the caller's ncclComm_t (passed as void*; librccl is resolved with dlopen, preferring the copy the
  * process has already loaded).  tsqr_mi_qr_f32_dist_cb: caller-supplied collectives (blocking or stream-ordered; in place sum /
- * gather in rank order), e.g. torch.distributed over gloo -- what the two-process tests use. */
+ * gather in rank order), e.g. torch.distributed over gloo -- what the multi-process tests use. */
 size_t tsqr_mi_working_q_size_dist(size_t m_local, size_t n, int nranks);
 size_t tsqr_mi_working_r_size_dist(size_t m_local, size_t n, int nranks);
 int tsqr_mi_qr_f32_dist(int mode, int reorth,
