@@ -5,9 +5,14 @@ M = 2^20 x N = 64 per GPU, fp32_tc_cor).
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+A bare `python bench.py --gpus N` (N > 1, no launcher in front: WORLD_SIZE unset) starts its own N ranks: before anything touches
+the GPU it runs the torch.distributed.run command above as a child process, forwards its output and exits with its status.
+
 A "step" is one blocking mtk::qr::qr call (C ABI tsqr_mi_qr_f32, or the row-partitioned driver for N > 1) on a
-synthetic U(-1,1) matrix already resident in HBM.  Weak scaling: every rank owns 2^20 rows (N = 8 is BASELINE's C4,
+synthetic matrix already resident in HBM.  Weak scaling: every rank owns 2^20 rows (N = 8 is BASELINE's C4,
 2^23 x 64).  For n <= 64 the engine does not modify A, so no restore is needed between steps.
+--workload selects the BASELINE.json configuration: c2 (default, the headline: 2^20 x 64 fp32_tc_cor U(-1,1)), c3 (2^20 x 128,
+--mode fp32_tc_cor | fp32_notc), c5 (latms cond 1e8, 2^20 x 64, Reorthogonalize = true); c4 is `--gpus 8` of c2's per-GPU shape.
 Prints ONE JSON line on rank 0 (contract in the task prompt) including `roofline` and `cpu_baseline` objects.
 """
 import argparse
@@ -127,19 +132,27 @@ def pmc_traffic(kernel_class, m, n, mode):
     return None, None
 
 
-def main():
+WORKLOADS = {
+    # BASELINE.json configs[1], [2], [4] ([3] = `--gpus 8` of c2's per-GPU shape; [0] is the CPU-runnable LAPACK case, tests/test_gpu_configs.py)
+    "c2": dict(m=1 << 20, n=64, mode="fp32_tc_cor", reorth=0, input="uniform", cpu_rows=1 << 20),
+    "c3": dict(m=1 << 20, n=128, mode="fp32_tc_cor", reorth=0, input="uniform", cpu_rows=1 << 19),
+    "c5": dict(m=1 << 20, n=64, mode="fp32_tc_cor", reorth=1, input="latms_cond1e8", cpu_rows=1 << 20),
+}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)       # reference protocol: 1 warm-up + C = 16 calls (src/test.cu:289-309); a few more
-    # untimed calls let the clocks settle (0.193 vs 0.20 ms per call)
+    ap.add_argument("--steps", type=int, default=32)       # reference protocol: 1 warm-up + C = 16 calls (src/test.cu:289-309)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--m", type=int, default=1 << 20, help="rows per GPU")
-    ap.add_argument("--n", type=int, default=64)
-    ap.add_argument("--mode", default="fp32_tc_cor", choices=["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor"])
-    ap.add_argument("--reorth", type=int, default=0)
-    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 20)   # the whole headline matrix: ~15 s of CPU work on 16 host threads
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="BASELINE.json configuration (see the module docstring)")
+    ap.add_argument("--m", type=int, default=None, help="rows per GPU (default: the workload's)")
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--mode", default=None, choices=["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor"])
+    ap.add_argument("--reorth", type=int, default=None)
+    ap.add_argument("--cpu-sample-rows", type=int, default=None)   # c2: the whole headline matrix, ~15 s of CPU work on 16 host threads
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--steady-after", type=int, default=300, help="untimed calls before the extra steady-state timing leg (0 = skip it)")
+    ap.add_argument("--no-first-window", action="store_true", help="skip the extra timing window at process start (profiling runs)")
     ap.add_argument("--gram-waves", type=int, default=0)
     ap.add_argument("--apply-waves", type=int, default=0)
     ap.add_argument("--policy", type=int, default=0)
@@ -148,172 +161,231 @@ def main():
                     help="transport of the row-partitioned driver's two exchanges: raw RCCL communicator (C calls ncclAllReduce itself, "
                          "no Python between kernels) or torch.distributed callbacks; auto = rccl when every rank can create it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend; gloo only to rehearse the multi-rank logic with several ranks on ONE GPU")
+                    help="process-group backend; gloo only to rehearse the multi-rank logic with several ranks on ONE GPU (or none)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="NO GPU: the per-rank executor is the numpy test double of tests/dist_double.py.  Exercises the launcher, the "
+                         "collectives and the JSON plumbing on CPU; the numbers say nothing about the product and are labelled so")
     ap.add_argument("--ld-pad", type=int, default=0, help="leading dimension = m + pad (experiments on DRAM channel mapping)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    w = WORKLOADS[args.workload]
+    for k in ("m", "n", "mode", "reorth"):
+        if getattr(args, k) is None:
+            setattr(args, k, w[k])
+    if args.cpu_sample_rows is None:
+        args.cpu_sample_rows = min(w["cpu_rows"], args.m)
+    args.input = w["input"]
+    return args
+
+
+def spawn_own_ranks(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this file under torch.distributed.run as ONE child process
+    (this process has not touched the GPU and never will), forward its output, return its exit status."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    # the ranks' own arguments travel in the environment: the launcher's argument parser chokes on options of the script that
+    # happen to abbreviate one of its own (--m is "ambiguous" to it even behind the script name)
+    env = dict(os.environ, TSQR_BENCH_ARGV=json.dumps(list(argv)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    return subprocess.call(cmd, env=env)
+
+
+def make_input(args, m, n, m_glob, rank, dev):
+    if args.input == "uniform" or args.rehearse:
+        return synth_block(m, n, m_glob, rank * m, 0, dev)
+    # C5: latms-style A = U diag(s) V^T with the reference's singular-value draw (src/test_cond.cu:31-50), cond 1e8, fixed seed
+    from tsqr_gpu_amd import harness
+    return harness.get_rand_matrix_with_cond_number(m, n, 1e8, seed=5, device=dev)
+
+
+def main():
+    argv = sys.argv[1:]
+    if not argv and os.environ.get("TSQR_BENCH_ARGV"):       # a rank started by spawn_own_ranks
+        argv = json.loads(os.environ["TSQR_BENCH_ARGV"])
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:    # bare multi-GPU invocation: become the launcher, before any GPU call
+        sys.exit(spawn_own_ranks(argv, args.gpus))
 
     from tsqr_gpu_amd import blockqr as bq
-    bq.lib()                                                # fail loudly if the HIP library is missing
-    bq.lib().tsqr_mi_set_tuning2(args.gram_waves, args.apply_waves)
-    bq.set_policy(args.policy)
+    if not args.rehearse:
+        bq.lib()                                            # fail loudly if the HIP library is missing
+        bq.lib().tsqr_mi_set_tuning2(args.gram_waves, args.apply_waves)
+        bq.set_policy(args.policy)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    if args.backend == "gloo":                               # rehearsal: ranks may share a device
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    gpu = not args.rehearse
+    if gpu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (--rehearse runs the launcher/collective plumbing on a CPU double)"
+        if args.backend == "gloo":                           # rehearsal: ranks may share a device
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+    else:
+        assert args.backend == "gloo", "--rehearse runs on CPU: use --backend gloo"
     if world > 1 or (args.force_dist and "RANK" in os.environ):
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if gpu else torch.device("cpu")
     if world > 1:                                           # communicator set-up (lazy in RCCL) must never land in the timed region
         warm = torch.zeros(2560, dtype=torch.float64, device=dev)
         dist.all_reduce(warm)
-        torch.cuda.synchronize()
+        if gpu:
+            torch.cuda.synchronize()
     m, n = args.m, args.n
     m_glob = m * world
+    assert world == 1 or n <= 64, "the row-partitioned path factors one 64-wide panel (c3 is a one-GPU workload)"
+    assert world == 1 or args.input == "uniform", "c5 is a one-GPU workload"
     mode = bq.compute_mode[args.mode]
 
     ld = m + args.ld_pad
-    d_a = synth_block(m, n, m_glob, rank * m, 0, dev)
+    d_a = make_input(args, m, n, m_glob, rank, dev)
     d_q = torch.empty(n, ld, dtype=torch.float32, device=dev)[:, :m]
     if args.ld_pad:
         a_pad = torch.zeros(n, ld, dtype=torch.float32, device=dev)
         a_pad[:, :m] = d_a
         d_a = a_pad[:, :m]
+    a_keep = d_a.clone() if n > 64 else None                 # n > 64: the engine may overwrite A (it does not on the one-panel path)
     d_r = torch.zeros(n, n, dtype=torch.float32, device=dev)
     eng = None
-    if world == 1 and not args.force_dist:
+    if args.rehearse:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from dist_double import NumpyRowBackend
+        from tsqr_gpu_amd import dist as tdist
+        eng = tdist.RowPartitionedQR(mode, m, n, backend=NumpyRowBackend(n, tdist.TorchCollectives()))
+
+        def run_steps(k):
+            for _ in range(k):
+                assert eng.qr(d_q, ld, d_r, d_a, ld, reorthogonalize=bool(args.reorth)) == 0
+    elif world == 1 and not args.force_dist:
         bf = bq.buffer(mode, bool(args.reorth), device=dev)
         bf.allocate(m, n)
+        loop = bq.bind_loop(d_q, ld, d_r, n, d_a, ld, m, n, bf)  # K blocking calls issued by ONE C loop (tsqr_mi_qr_f32_loop): what a C++
+        # caller's loop costs (the reference's speed protocol is such a loop, src/test.cu:299-309), no interpreter time between calls
 
-        call = bq.bind(d_q, ld, d_r, n, d_a, ld, m, n, bf)   # arguments marshalled once, as in a C++ caller's loop
-
-        def step():
-            st = call()
+        def run_steps(k):
+            st = loop(k)
             assert st == 0, st
     else:
         from tsqr_gpu_amd import dist as tdist
         eng = tdist.RowPartitionedQR(mode, m, n, comm=args.dist_comm)    # one C call per step; RCCL called from C on this stream
+        dloop = eng.bind_loop(d_q, ld, d_r, d_a, ld, reorthogonalize=bool(args.reorth))
 
-        dcall = eng.bind(d_q, ld, d_r, d_a, ld, reorthogonalize=bool(args.reorth))   # arguments marshalled once here too
-
-        def step():
-            st = dcall()
+        def run_steps(k):
+            st = dloop(k)
             assert st == 0, st                              # (blocking like the single-GPU call: complete on return)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if gpu:
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms_per_step = dt / args.steps * 1e3
-    flops = f_qr(m_glob, n)
-    gflops = flops / (ms_per_step * 1e-3) / 1e9
+    def timed_window():
+        """The contract's measurement: W untimed warm-up steps, then exactly K steps between barrier + synchronize, MAX over ranks."""
+        run_steps(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt / args.steps * 1e3
 
-    # accuracy of the last step, evaluated on the device in fp64 (global Q: all-reduce of Q_p^T Q_p)
+    # 1. one step, checked: accuracy of the factorisation evaluated in fp64 (global Q: all-reduce of Q_p^T Q_p), A untouched
+    run_steps(1)
+    barrier()
     q64 = d_q.double()
     gram = q64 @ q64.T
     r64 = d_r.double().T.contiguous()
-    res_num = ((r64.T @ q64) - d_a.double()).pow(2).sum().reshape(1)
-    res_den = d_a.double().pow(2).sum().reshape(1)
+    a64 = (a_keep if a_keep is not None else d_a).double()
+    res_num = ((r64.T @ q64) - a64).pow(2).sum().reshape(1)
+    res_den = a64.pow(2).sum().reshape(1)
     if world > 1:
         dist.all_reduce(gram); dist.all_reduce(res_num); dist.all_reduce(res_den)
     orth_fro = float((gram - torch.eye(n, device=dev, dtype=torch.float64)).norm().item())
     residual = float(torch.sqrt(res_num / res_den).item())
-    del q64
+    a_untouched = True if a_keep is None else bool(torch.equal(a_keep, d_a))
+    if not a_untouched:                                      # panel path for n > 64 (ill-conditioned input): every step needs a fresh A
+        raise SystemExit("bench.py: the engine overwrote A on this workload; timing repeated calls on it would not measure the workload")
+    del q64, a64
 
-    # per-kernel-class timing with HIP events on the engine's stream, same number of steps
+    # 2. a timing window at process start (reported as `first_window`, not as `value`): the first ~30 calls of a process run
+    #    5-8 % slower than all later ones (GPU clock / power settling after idle: tools/ramp.py, profiles/r02_experiment_log.md)
+    first_ms = None if (args.no_first_window or args.rehearse) else timed_window()
+
+    # 3. per-kernel-class timing with HIP events on the engine's stream, K steps (the roofline leg)
     prof = None
-    bq.profile_enable(True)
-    for _ in range(args.steps):
-        step()
-    barrier()
-    prof = bq.profile_read()
-    bq.profile_enable(False)
+    if gpu:
+        bq.profile_enable(True)
+        run_steps(args.steps)
+        barrier()
+        prof = bq.profile_read()
+        bq.profile_enable(False)
 
-    # Steady state, reported BESIDE the contract's number (never instead of it): the first ~30 calls of a process run 5-8 % slower
-    # than the rest (clock / power settling: tools/ramp.py shows 177-180 us for calls 10..30 and 165 us from call ~30 on at the
-    # headline size), and a run with 5 warm-up + 20 timed steps sits exactly there.  The same K steps are timed once more after
-    # `--steady-after` further untimed calls (the same count on every rank: the steps are collective).
-    steady_ms = None
-    if args.steady_after > 0:
-        for _ in range(args.steady_after):
-            step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dts = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([dts], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dts = float(tt.item())
-        steady_ms = dts / args.steps * 1e3
+    # 4. the contract's window
+    ms_per_step = timed_window()
+    flops = f_qr(m_glob, n)
+    gflops = flops / (ms_per_step * 1e-3) / 1e9
 
     if rank == 0:
-        dom = max(prof, key=lambda k: prof[k][0])
-        dom_ms, dom_launches = prof[dom]
-        per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
-        # algorithmic work of one launch of the dominant kernel
-        if dom == "apply":                                  # Q = A * inverse(R): read A, write Q
-            bound, alg_bytes, alg_flops = "hbm", 8.0 * m * n, 2.0 * m * n * n
-        elif dom == "gram":                                 # G = A^T A: read A once
-            bound, alg_bytes, alg_flops = "hbm", 4.0 * m * n, 2.0 * m * n * n
-        else:                                               # Householder fold: R factor of the local block
-            bound, alg_bytes, alg_flops = "mfma", 4.0 * m * n, f_r(m, n)
-        if bound == "hbm":
-            ach, peak, unit = alg_bytes / per_launch_s / 1e9, PEAK_HBM_TBS * 1e3, "GB/s"
-        else:
-            ach, peak, unit = alg_flops / per_launch_s / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
-        traffic, traffic_source = pmc_traffic(dom, m, n, args.mode)
-        engine_name = bq.ENGINE_NAMES.get(eng.last_engine if eng is not None else bq.last_engine(), "?")
-        roofline = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                    "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
-                    "note": "HBM fractions are fabric-side: the same A is factored every step (the reference's own protocol, "
-                            "src/test.cu:299-309) and stays largely resident in the 256 MiB Infinity Cache between the two passes "
-                            "and between steps; FETCH_SIZE counts those hits as memory-side requests",
-                    "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
-                    "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
-                    "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
-                    "r_factor_engine": engine_name,
-                    "whole_path": {"tflops": gflops / 1e3 / world, "peak_tflops_f32_matrix": PEAK_F32_MATRIX_TFLOPS,
-                                   "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
-                                   "algorithmic_gbs": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e9,
-                                   "frac_hbm_peak": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e12 / PEAK_HBM_TBS}}
+        engine_name = "numpy-double (rehearsal)" if args.rehearse else bq.ENGINE_NAMES.get(eng.last_engine if eng is not None else bq.last_engine(), "?")
+        roofline = None
+        if prof is not None:
+            dom = max(prof, key=lambda k: prof[k][0])
+            dom_ms, dom_launches = prof[dom]
+            per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
+            # algorithmic work of one launch of the dominant kernel (DESIGN.md section 4)
+            if dom == "apply":                                  # Q = A * inverse(R): read A, write Q
+                bound, alg_bytes, alg_flops = "hbm", 8.0 * m * n, 2.0 * m * n * n
+            elif dom == "gram":                                 # G = A^T A: read A once
+                bound, alg_bytes, alg_flops = "hbm", 4.0 * m * n, 2.0 * m * n * n
+            else:                                               # Householder fold: R factor of the local block
+                bound, alg_bytes, alg_flops = "mfma", 4.0 * m * n, f_r(m, n)
+            if bound == "hbm":
+                ach, peak, unit = alg_bytes / per_launch_s / 1e9, PEAK_HBM_TBS * 1e3, "GB/s"
+            else:
+                ach, peak, unit = alg_flops / per_launch_s / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
+            traffic, traffic_source = pmc_traffic(dom, m, n, args.mode) if args.workload == "c2" else (None, None)
+            roofline = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                        "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
+                        "note": "HBM fractions are fabric-side: the same A is factored every step (the reference's own protocol, "
+                                "src/test.cu:299-309) and a 256 MiB A stays largely resident in the 256 MiB Infinity Cache between the two "
+                                "passes and between steps; FETCH_SIZE counts those hits as memory-side requests",
+                        "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
+                        "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+                        "r_factor_engine": engine_name,
+                        "whole_path": {"tflops": gflops / 1e3 / world, "peak_tflops_f32_matrix": PEAK_F32_MATRIX_TFLOPS,
+                                       "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
+                                       "algorithmic_gbs": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e9,
+                                       "frac_hbm_peak": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e12 / PEAK_HBM_TBS}}
+        inp = "U(-1,1)" if args.input == "uniform" else "latms cond 1e8 (src/test_cond.cu:31-50 spectrum, seed 5)"
         out = {"metric": "tsqr_gflops", "value": gflops, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
-               "config": {"workload": "M=2^%d x N=%d per GPU, %s, reorth=%d, U(-1,1); global %d x %d; F_QR=4MN^2-4/3N^3; R-factor engine: %s" % (
-                   int(np.log2(m)) if m & (m - 1) == 0 else -1, n, args.mode, args.reorth, m_glob, n, engine_name),
+               "config": {"workload": "%s: M=2^%d x N=%d per GPU, %s, reorth=%d, %s; global %d x %d; F_QR=4MN^2-4/3N^3; R-factor engine: %s" % (
+                   args.workload, int(np.log2(m)) if m & (m - 1) == 0 else -1, n, args.mode, args.reorth, inp, m_glob, n, engine_name),
                    "engine": engine_name, "m_per_gpu": m, "n": n, "mode": args.mode, "reorthogonalize": bool(args.reorth),
                    "parallelism": "row-partitioned x%d" % world,
                    "dist_transport": (eng.transport if eng is not None else None)},
                "orth_fro": orth_fro, "orth_ref_metric": orth_fro / np.sqrt(n), "residual": residual,
+               "window_order": "1 checked step, first_window (W + K), K steps under HIP events, then the W + K window `value` is taken from",
                "roofline": roofline}
-        if steady_ms is not None:
-            out["steady_state"] = {"ms_per_step": steady_ms, "value": flops / (steady_ms * 1e-3) / 1e9, "unit": "GFLOP/s",
-                                   "after_untimed_calls": args.warmup + 2 * args.steps + 8 + args.steady_after,
-                                   "note": "same K steps timed again later in the process; `value` above is the contract's number"}
-        if world == 1 and not args.no_cpu_baseline:
+        if args.rehearse:
+            out["rehearsal"] = True
+            out["data"] = "synthetic (CPU rehearsal with the numpy test double: NOT a measurement of the product)"
+        if first_ms is not None:
+            out["first_window"] = {"ms_per_step": first_ms, "value": flops / (first_ms * 1e-3) / 1e9, "unit": "GFLOP/s",
+                                   "note": "the same W + K window taken at process start, inside the GPU's clock / power transient after idle"}
+        if world == 1 and not args.no_cpu_baseline and not args.rehearse:
             out["cpu_baseline"] = cpu_baseline(n, args.mode, args.cpu_sample_rows)
         print(json.dumps(out))
     if dist.is_initialized():

@@ -70,6 +70,14 @@ int tsqr_mi_qr_f32(int mode, int reorth,
                    size_t m, size_t n,
                    void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
                    void* stream);
+/* `count` back-to-back blocking calls of tsqr_mi_qr_f32 with the same arguments -- the loop of the reference's speed protocol
+ * (reference src/test.cu:299-309) on this side of the ABI, so that a host in an interpreted language times what a C++ caller's
+ * loop costs.  Returns the first non-zero state. */
+int tsqr_mi_qr_f32_loop(int count, int mode, int reorth,
+                        float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                        size_t m, size_t n,
+                        void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
+                        void* stream);
 
 /*
  * Staged entry points used by the row-partitioned multi-GPU path: every rank
@@ -112,9 +120,15 @@ int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t 
  *                       all ranks by construction -- a NaN anywhere reaches everyone through the sum;
  *   Householder engine: all-gather of the n x n local R factors, every rank folds the same (nranks n) x n stack.
  * Work buffers: tsqr_mi_working_{q,r}_size_dist(m_local, n, nranks) elements; gather_buf: nranks*n*n floats.
- * tsqr_mi_qr_f32_dist: RCCL on the caller's ncclComm_t (passed as void*; librccl is resolved with dlopen, preferring the copy the
- * process has already loaded).  tsqr_mi_qr_f32_dist_cb: caller-supplied collectives (blocking or stream-ordered; in place sum /
- * gather in rank order), e.g. torch.distributed over gloo -- what the multi-process tests use. */
+ * The communicator and the collectives that run on it must come from ONE RCCL instance (a process may have two mapped: torch
+ * bundles a copy, /opt/rocm holds another), so the library never searches for librccl itself:
+ * tsqr_mi_qr_f32_dist_fn: the caller passes its ncclComm_t (as void*) together with the addresses of ncclAllReduce and ncclAllGather
+ *   taken from the library that created it (dlsym on that handle; Python: ctypes.cast(lib.ncclAllReduce, c_void_p)).
+ * tsqr_mi_qr_f32_dist: for a caller that LINKS RCCL (C++): the two entry points are looked up in the global symbol scope
+ *   (dlsym(RTLD_DEFAULT, ...)) -- the copy the caller's own ncclCommInitRank came from; TSQR_MI_ERROR_UNSUPPORTED when they are not there.
+ * tsqr_mi_qr_f32_dist_cb: caller-supplied collectives (blocking or stream-ordered; in place sum / gather in rank order), e.g.
+ *   torch.distributed over gloo -- what the multi-process tests use.
+ * *_loop: `count` back-to-back calls (see tsqr_mi_qr_f32_loop); every rank must pass the same count. */
 size_t tsqr_mi_working_q_size_dist(size_t m_local, size_t n, int nranks);
 size_t tsqr_mi_working_r_size_dist(size_t m_local, size_t n, int nranks);
 int tsqr_mi_qr_f32_dist(int mode, int reorth,
@@ -122,6 +136,16 @@ int tsqr_mi_qr_f32_dist(int mode, int reorth,
                         size_t m_local, size_t n,
                         void* wq, void* wr, float* gather_buf /* nranks*n*n floats */,
                         void* nccl_comm, int nranks, void* stream);
+int tsqr_mi_qr_f32_dist_fn(int mode, int reorth,
+                           float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                           size_t m_local, size_t n,
+                           void* wq, void* wr, float* gather_buf /* nranks*n*n floats */,
+                           void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream);
+int tsqr_mi_qr_f32_dist_fn_loop(int count, int mode, int reorth,
+                                float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                                size_t m_local, size_t n,
+                                void* wq, void* wr, float* gather_buf,
+                                void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream);
 typedef int (*tsqr_mi_allreduce_f64_cb)(void* user, double* buf /* device */, size_t count, void* stream);
 typedef int (*tsqr_mi_allgather_f32_cb)(void* user, const float* send /* device */, float* recv /* device, nranks*count */, size_t count, void* stream);
 int tsqr_mi_qr_f32_dist_cb(int mode, int reorth,
@@ -129,6 +153,11 @@ int tsqr_mi_qr_f32_dist_cb(int mode, int reorth,
                            size_t m_local, size_t n,
                            void* wq, void* wr, float* gather_buf,
                            tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream);
+int tsqr_mi_qr_f32_dist_cb_loop(int count, int mode, int reorth,
+                                float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                                size_t m_local, size_t n,
+                                void* wq, void* wr, float* gather_buf,
+                                tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream);
 
 /* Harness support (reference src/validation.cu:43-127, src/test.cu:147-165): accuracy metrics evaluated on the device in fp64.
  * scratch: n*n + 8 doubles of device memory.  out_host[0..4] = ||Q^T Q - I||_F^2, its diagonal part, its off-diagonal part,

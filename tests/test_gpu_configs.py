@@ -2,11 +2,13 @@
 fp64 (tsqr_mi_validate_f32): residual, ||Q^T Q - I||_F, R upper triangular.  C2 lives in test_gpu_parity.py::test_full_size_properties;
 C4's 8-GPU partitioning is covered by the gloo tests (CPU) and by the row-partitioned driver on one rank here."""
 import math
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -125,8 +127,9 @@ def test_c5_latms_cond_1e8_reorth(env, mode, spectrum):
 @pytest.mark.parametrize("mode,policy,want", [("fp32_tc_cor", 0, 3), ("fp32_notc", 0, 1), ("fp32_tc_cor", 1, 0)])
 @pytest.mark.parametrize("reorth", [0, 1])
 def test_cpp_dist_entry_point_over_rccl_single_rank(env, mode, policy, want, reorth):
-    """tsqr_mi_qr_f32_dist (the one-call C++ driver over an ncclComm_t) on a one-rank RCCL communicator created through
-    ctypes: exercises the dlopen'ed ncclAllReduce / ncclAllGather calls, the speculative apply and the Householder stack."""
+    """tsqr_mi_qr_f32_dist_fn (the one-call driver over an ncclComm_t) on a one-rank RCCL communicator created through ctypes; the
+    ncclAllReduce / ncclAllGather entry points handed to the C side come from the SAME library handle as the communicator (whichever
+    librccl copy that name resolves to).  Exercises the speculative apply and the Householder stack."""
     import ctypes
     torch, bq, harness, oracle = env
     try:
@@ -152,9 +155,10 @@ def test_cpp_dist_entry_point_over_rccl_single_rank(env, mode, policy, want, reo
         gather = torch.empty(n * n, device="cuda")
         bq.set_policy(policy)
         try:
-            st = bq.lib().tsqr_mi_qr_f32_dist(int(bq.compute_mode[mode]), reorth, d_q.data_ptr(), m, d_r.data_ptr(), n,
-                                              d_a.data_ptr(), m, m, n, wq.data_ptr(), wr.data_ptr(), gather.data_ptr(),
-                                              comm, 1, torch.cuda.current_stream().cuda_stream)
+            st = bq.lib().tsqr_mi_qr_f32_dist_fn(int(bq.compute_mode[mode]), reorth, d_q.data_ptr(), m, d_r.data_ptr(), n,
+                                                 d_a.data_ptr(), m, m, n, wq.data_ptr(), wr.data_ptr(), gather.data_ptr(),
+                                                 comm, ctypes.cast(rccl.ncclAllReduce, ctypes.c_void_p),
+                                                 ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p), 1, torch.cuda.current_stream().cuda_stream)
         finally:
             bq.set_policy(bq.POLICY_AUTO)
         torch.cuda.synchronize()
@@ -169,6 +173,28 @@ def test_cpp_dist_entry_point_over_rccl_single_rank(env, mode, policy, want, reo
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_cpp_caller_that_links_rccl(env):
+    """tests/cpp/sample_dist_rccl.cpp links -lrccl and passes its own ncclComm_t to tsqr_mi_qr_f32_dist: the library must take
+    ncclAllReduce / ncclAllGather from the global symbol scope (the caller's copy), for the Gram and the Householder exchange."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "sample_dist_rccl")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "sample_dist_rccl"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0 and "DIST SAMPLE OK" in out.stdout, out.stdout + out.stderr
+    assert "policy=0 engine=3" in out.stdout and "policy=1 engine=0" in out.stdout
+
+
+def test_dist_entry_without_entry_points_fails_cleanly(env):
+    """no communicator / no entry points: an error code and a message, never a crash or a silently loaded second RCCL"""
+    torch, bq, harness, oracle = env
+    t = torch.zeros(64 * 64, device="cuda")
+    st = bq.lib().tsqr_mi_qr_f32_dist_fn(3, 0, t.data_ptr(), 64, t.data_ptr(), 64, t.data_ptr(), 64, 64, 64, t.data_ptr(), t.data_ptr(),
+                                         t.data_ptr(), None, None, None, 1, torch.cuda.current_stream().cuda_stream)
+    assert st == 2 and "ncclComm_t" in bq.last_error()
 
 
 @pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])

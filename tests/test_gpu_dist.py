@@ -61,19 +61,51 @@ def _free_port():
 
 
 def _run(heights, n, mode="fp32_tc_cor", reorth=False, policy=0, cond=1.0):
+    import queue
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
     world = len(heights)                                      # (at most 4 here: the GPU box allows 6 processes on its card)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, heights, n, mode, reorth, policy, cond, out)) for r in range(world)]
+    procs = [ctx.Process(target=_guarded, args=(r, world, port, heights, n, mode, reorth, policy, cond, out)) for r in range(world)]
     for p in procs:
         p.start()
-    res = out.get(timeout=300)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    return res
+    try:
+        # a rank that fails puts its exception text on the queue at once; a rank that dies without a word is noticed by polling
+        res = None
+        for _ in range(300):
+            try:
+                res = out.get(timeout=1.0)
+                break
+            except queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    raise RuntimeError("a rank exited with %s" % [p.exitcode for p in procs])
+        assert res is not None, "no result within 300 s"
+        assert "error" not in res, res.get("error")
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        return res
+    finally:
+        # never leave a rank behind on the card (blocked in a gloo collective its partner will not enter any more)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
+
+
+def _guarded(rank, *args):
+    out = args[-1]
+    try:
+        _worker(rank, *args)
+    except BaseException as e:                                # surfaces at once in the parent instead of after its timeout
+        import traceback
+        out.put({"error": "rank %d: %s\n%s" % (rank, e, traceback.format_exc())})
+        raise
 
 
 def _check(res, oracle, orth_tol=5e-6, r_tol=1e-5):

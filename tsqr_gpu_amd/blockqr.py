@@ -45,6 +45,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_set_policy", "tsqr_mi_last_engine", "tsqr_mi_set_tuning2",
     "tsqr_mi_gram_elems", "tsqr_mi_gram_f32", "tsqr_mi_chol_f32", "tsqr_mi_chol_status", "tsqr_mi_stream_wait", "tsqr_mi_apply_z_f32", "tsqr_mi_validate_f32",
     "tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist", "tsqr_mi_qr_f32_dist_cb",
+    "tsqr_mi_qr_f32_loop", "tsqr_mi_qr_f32_dist_fn", "tsqr_mi_qr_f32_dist_fn_loop", "tsqr_mi_qr_f32_dist_cb_loop",
 ]
 
 _lib = None
@@ -97,6 +98,14 @@ def lib():
     L.tsqr_mi_qr_f32_dist.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, ci, vp]
     L.tsqr_mi_qr_f32_dist_cb.restype = ci
     L.tsqr_mi_qr_f32_dist_cb.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, ci, vp]
+    L.tsqr_mi_qr_f32_loop.restype = ci
+    L.tsqr_mi_qr_f32_loop.argtypes = [ci] + L.tsqr_mi_qr_f32.argtypes
+    L.tsqr_mi_qr_f32_dist_fn.restype = ci
+    L.tsqr_mi_qr_f32_dist_fn.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, ci, vp]
+    L.tsqr_mi_qr_f32_dist_fn_loop.restype = ci
+    L.tsqr_mi_qr_f32_dist_fn_loop.argtypes = [ci] + L.tsqr_mi_qr_f32_dist_fn.argtypes
+    L.tsqr_mi_qr_f32_dist_cb_loop.restype = ci
+    L.tsqr_mi_qr_f32_dist_cb_loop.argtypes = [ci] + L.tsqr_mi_qr_f32_dist_cb.argtypes
     for name in ("tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist"):
         getattr(L, name).restype = sz
         getattr(L, name).argtypes = [sz, sz, ci]
@@ -219,6 +228,29 @@ def bind(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonali
 
     def call():
         st = fn(*args)
+        if st < 0:
+            raise RuntimeError("tsqr_mi_qr_f32 failed: %s" % last_error())
+        return st
+    call._keep = keep
+    return call
+
+
+def bind_loop(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
+    """Like bind(), but the callable takes a count k and issues k back-to-back blocking calls from ONE C loop (tsqr_mi_qr_f32_loop):
+    the reference's speed protocol (src/test.cu:299-309) without interpreter time between the calls."""
+    import torch
+    mode = bf.mode if mode is None else compute_mode(mode)
+    reorth = bf.reorthogonalize if reorthogonalize is None else bool(reorthogonalize)
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    fn = lib().tsqr_mi_qr_f32_loop
+    args = (ci(int(mode)), ci(int(reorth)), vp(_ptr(q)), sz(ldq), vp(_ptr(r)), sz(ldr), vp(_ptr(a)), sz(lda), sz(m), sz(n),
+            vp(_ptr(bf.dwq)), vp(_ptr(bf.dwr)), vp(_ptr(bf.dw_reorth_r)), vp(_ptr(bf.dl)), vp(_ptr(bf.hl)), vp(stream.cuda_stream))
+    keep = (q, r, a, bf, stream)
+
+    def call(k=1):
+        st = fn(ci(int(k)), *args)
         if st < 0:
             raise RuntimeError("tsqr_mi_qr_f32 failed: %s" % last_error())
         return st

@@ -240,19 +240,11 @@ struct Comm {
 		return -1;
 	}
 };
-void* rccl_symbol(const char* name) {
-	static std::atomic<void*> h{nullptr};
-	void* lib = h.load();
-	if (!lib) {
-		// the copy a host framework (torch) has already loaded first: two RCCL instances in one process must not meet
-		lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-		if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-		if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-		if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-		h.store(lib);
-	}
-	return lib ? dlsym(lib, name) : nullptr;
-}
+// ncclAllReduce / ncclAllGather of a caller that LINKS RCCL itself (C++): the symbols are then in the global scope and this lookup
+// returns the very copy the caller created its communicator with.  No soname search and no dlopen: a second RCCL instance (torch
+// bundles one, /opt/rocm has another) must never meet a communicator of the first.  Callers that loaded RCCL privately (Python
+// ctypes: RTLD_LOCAL) pass the entry points of that very handle instead (tsqr_mi_qr_f32_dist_fn).
+void* rccl_symbol(const char* name) { return dlsym(RTLD_DEFAULT, name); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // per-call context
@@ -296,13 +288,20 @@ thread_local OwnPinned t_own;
 // Is h_wl pinned host memory the device can write, and does it hold the eight words the engine uses?  mtk::qr::buffer allocates it
 // with hipHostMalloc, but a caller that sized it with the REFERENCE's get_working_l_size (batch_size + 1 words: 2..5 for m <= 128)
 // must not be written past its end -- then (and for pageable memory) the thread's own pinned words are used.
+// (the answer for the last h_wl of this host thread is remembered: the query sits in front of the first launch of every call, and a
+// caller's loop passes the same buffer every time.  A buffer freed and re-allocated at the same address as PAGEABLE memory between two
+// calls would be mistaken for the pinned one; mtk::qr::buffer always allocates hl pinned.)
+struct HostSigCache { unsigned* h_wl = nullptr; unsigned* dev = nullptr; };
+thread_local HostSigCache t_hsig_cache;
 void resolve_host_sig(Ctx& c, unsigned* h_wl, size_t m) {
 	c.hsig = HostSig{};
 	if (!g_set.host_status) return;
 	if (h_wl && ref_bs(m) + 1 >= 8) {
+		if (t_hsig_cache.h_wl == h_wl) { c.hsig.host = h_wl; c.hsig.dev = t_hsig_cache.dev; return; }
 		hipPointerAttribute_t at{};
 		if (hipPointerGetAttributes(&at, h_wl) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
 			c.hsig.host = h_wl; c.hsig.dev = reinterpret_cast<unsigned*>(at.devicePointer);
+			t_hsig_cache.h_wl = h_wl; t_hsig_cache.dev = c.hsig.dev;
 			return;
 		}
 		(void)hipGetLastError();
@@ -1039,7 +1038,7 @@ int qr_dist_common(Ctx& c, int mode, int reorth, float* q, size_t ldq, float* r,
 
 extern "C" {
 
-int tsqr_mi_version(void) { return 200; }
+int tsqr_mi_version(void) { return 300; }
 const char* tsqr_mi_last_error(void) { return t_last_error.c_str(); }
 
 size_t tsqr_mi_batch_size_log2(size_t m) { return ref_bs_log2(m); }
@@ -1119,17 +1118,43 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	return qr_core(c, engine, reorth, q, ldq, r, ldr, a, lda, m, n);
 }
 
+// `count` back-to-back blocking calls with the same arguments: the reference's speed protocol (src/test.cu:299-309 is such a C++ loop
+// around the blocking call).  Returns the first non-zero state.
+int tsqr_mi_qr_f32_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                        size_t m, size_t n, void* wq_v, void* wr_v, float* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
+	for (int i = 0; i < count; i++) {
+		const int st = tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
+		if (st) return st;
+	}
+	return TSQR_MI_SUCCESS;
+}
+
 // ---- row-partitioned TSQR: one call per rank, the same ladder as tsqr_mi_qr_f32 with the exchange hooks switched on ----
+int tsqr_mi_qr_f32_dist_fn(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                           size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
+                           void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream) {
+	if (!nccl_comm || !nccl_allreduce_fn || !nccl_allgather_fn) {
+		t_last_error = "row-partitioned call needs an ncclComm_t and the ncclAllReduce / ncclAllGather entry points of the library that created it";
+		return TSQR_MI_ERROR_UNSUPPORTED;
+	}
+	Ctx c;
+	c.comm.nccl = nccl_comm;
+	c.comm.nccl_allreduce = reinterpret_cast<nccl_allreduce_t>(nccl_allreduce_fn);
+	c.comm.nccl_allgather = reinterpret_cast<nccl_allgather_t>(nccl_allgather_fn);
+	c.comm.gather_buf = gather_buf;
+	return qr_dist_common(c, mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, nranks, stream);
+}
 int tsqr_mi_qr_f32_dist(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                         size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
                         void* nccl_comm, int nranks, void* stream) {
-	Ctx c;
-	c.comm.nccl = nccl_comm;
-	c.comm.nccl_allreduce = reinterpret_cast<nccl_allreduce_t>(rccl_symbol("ncclAllReduce"));
-	c.comm.nccl_allgather = reinterpret_cast<nccl_allgather_t>(rccl_symbol("ncclAllGather"));
-	c.comm.gather_buf = gather_buf;
-	if (!nccl_comm || !c.comm.nccl_allreduce || !c.comm.nccl_allgather) { t_last_error = "librccl.so / ncclAllReduce / ncclAllGather not found"; return TSQR_MI_ERROR_UNSUPPORTED; }
-	return qr_dist_common(c, mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, nranks, stream);
+	void* ar = rccl_symbol("ncclAllReduce");
+	void* ag = rccl_symbol("ncclAllGather");
+	if (!ar || !ag) {
+		t_last_error = "ncclAllReduce / ncclAllGather are not in the global symbol scope (the caller does not link RCCL): "
+		               "pass the entry points of the library that created the communicator to tsqr_mi_qr_f32_dist_fn";
+		return TSQR_MI_ERROR_UNSUPPORTED;
+	}
+	return tsqr_mi_qr_f32_dist_fn(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, nccl_comm, ar, ag, nranks, stream);
 }
 int tsqr_mi_qr_f32_dist_cb(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                            size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
@@ -1139,6 +1164,25 @@ int tsqr_mi_qr_f32_dist_cb(int mode, int reorth, float* q, size_t ldq, float* r,
 	c.comm.cb_allreduce = allreduce; c.comm.cb_allgather = allgather; c.comm.cb_user = user;
 	c.comm.gather_buf = gather_buf;
 	return qr_dist_common(c, mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, nranks, stream);
+}
+int tsqr_mi_qr_f32_dist_fn_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                                size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
+                                void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream) {
+	for (int i = 0; i < count; i++) {
+		const int st = tsqr_mi_qr_f32_dist_fn(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, nccl_comm,
+		                                      nccl_allreduce_fn, nccl_allgather_fn, nranks, stream);
+		if (st) return st;
+	}
+	return TSQR_MI_SUCCESS;
+}
+int tsqr_mi_qr_f32_dist_cb_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                                size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
+                                tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream) {
+	for (int i = 0; i < count; i++) {
+		const int st = tsqr_mi_qr_f32_dist_cb(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, allreduce, allgather, user, nranks, stream);
+		if (st) return st;
+	}
+	return TSQR_MI_SUCCESS;
 }
 
 // ---- staged entry points (building blocks; every call builds its own context) ----

@@ -13,7 +13,9 @@ the same ladder as the single-GPU call, stream-ordered, with two exchange hooks
 Transport of the hooks:
   * RcclComm: a raw ncclComm_t created through ctypes on the librccl the process has already loaded (unique id from rank 0,
     broadcast over torch.distributed); the C code then calls ncclAllReduce / ncclAllGather itself on the caller's stream -- no
-    Python and no host wait between the kernels of a call.  This is what bench.py --gpus N uses.
+    Python and no host wait between the kernels of a call.  The addresses of those two entry points are taken from the SAME
+    library handle that created the communicator and travel with it into the C call (tsqr_mi_qr_f32_dist_fn): a process can have
+    two RCCL copies mapped (torch's bundled one and /opt/rocm's) and they must never meet.  This is what bench.py --gpus N uses.
   * TorchCollectives: callbacks into torch.distributed (any backend).  The two-process tests run the product engine with it over
     gloo on one GPU, and bench.py falls back to it when a raw communicator cannot be created.
 
@@ -81,7 +83,8 @@ class RcclComm:
                 break
             except OSError:
                 continue
-        ok = lib is not None and all(hasattr(lib, s) for s in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy"))
+        ok = lib is not None and all(hasattr(lib, s) for s in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy",
+                                                               "ncclAllReduce", "ncclAllGather"))
         backend = dist.get_backend(group)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
@@ -111,6 +114,10 @@ class RcclComm:
                 lib.ncclCommDestroy(comm)
             raise RuntimeError("ncclCommInitRank failed on at least one rank (%d here)" % rc)
         self.comm = comm
+        # the collectives of THIS library instance, as plain addresses for the C driver
+        self.allreduce_fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p)
+        self.allgather_fn = ctypes.cast(lib.ncclAllGather, ctypes.c_void_p)
+        self.lib_path = getattr(lib, "_name", None)
 
     def destroy(self):
         if self.comm is not None:
@@ -171,13 +178,23 @@ class HipBackend:
     def last_engine(self):
         return bq.last_engine()                        # (per host thread: the engine of this thread's last call)
 
+    def _check_block(self, m_local):
+        """The work buffers were sized for the constructor's m_local; a taller block would make the kernels write past them
+        (the C side cannot see the allocation).  Shorter blocks are fine."""
+        L = bq.lib()
+        if (L.tsqr_mi_working_q_size_dist(m_local, self.n, self.world) > self.wq.numel() or
+                L.tsqr_mi_working_r_size_dist(m_local, self.n, self.world) > self.wr.numel()):
+            raise ValueError("row block of %d rows needs larger work buffers than this engine allocated for %d rows: "
+                             "construct RowPartitionedQR with the largest block height" % (m_local, self.m_local))
+
     def qr_dist(self, q, ldq, r, ldr, a, lda, m_local, reorth):
+        self._check_block(m_local)
         st = torch.cuda.current_stream().cuda_stream   # the callbacks issue torch work on the current stream: it must be this one
         L = bq.lib()
         if self.comm is not None:
-            rc = L.tsqr_mi_qr_f32_dist(int(self.mode), int(reorth), q.data_ptr(), ldq, r.data_ptr(), ldr, a.data_ptr(), lda,
-                                       m_local, self.n, self.wq.data_ptr(), self.wr.data_ptr(), self.gather.data_ptr(),
-                                       self.comm.comm, self.world, st)
+            rc = L.tsqr_mi_qr_f32_dist_fn(int(self.mode), int(reorth), q.data_ptr(), ldq, r.data_ptr(), ldr, a.data_ptr(), lda,
+                                          m_local, self.n, self.wq.data_ptr(), self.wr.data_ptr(), self.gather.data_ptr(),
+                                          self.comm.comm, self.comm.allreduce_fn, self.comm.allgather_fn, self.world, st)
         else:
             self._cb_error = None
             rc = L.tsqr_mi_qr_f32_dist_cb(int(self.mode), int(reorth), q.data_ptr(), ldq, r.data_ptr(), ldr, a.data_ptr(), lda,
@@ -190,21 +207,25 @@ class HipBackend:
         return rc
 
 
-    def bind_dist(self, q, ldq, r, ldr, a, lda, m_local, reorth):
-        """qr_dist with every argument marshalled once (as blockqr.bind): a zero-argument callable = one C-ABI call per invocation."""
+    def bind_dist(self, q, ldq, r, ldr, a, lda, m_local, reorth, loop=False):
+        """qr_dist with every argument marshalled once (as blockqr.bind): a zero-argument callable = one C-ABI call per invocation.
+        loop = True: the callable takes a count k and issues k back-to-back calls from one C loop (every rank the same k)."""
+        self._check_block(m_local)
         st = torch.cuda.current_stream()
         vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         L = bq.lib()
         head = (ci(int(self.mode)), ci(int(reorth)), vp(q.data_ptr()), sz(ldq), vp(r.data_ptr()), sz(ldr), vp(a.data_ptr()), sz(lda),
                 sz(m_local), sz(self.n), vp(self.wq.data_ptr()), vp(self.wr.data_ptr()), vp(self.gather.data_ptr()))
         if self.comm is not None:
-            fn, args = L.tsqr_mi_qr_f32_dist, head + (self.comm.comm, ci(self.world), vp(st.cuda_stream))
+            fn = L.tsqr_mi_qr_f32_dist_fn_loop if loop else L.tsqr_mi_qr_f32_dist_fn
+            args = head + (self.comm.comm, self.comm.allreduce_fn, self.comm.allgather_fn, ci(self.world), vp(st.cuda_stream))
         else:
-            fn, args = L.tsqr_mi_qr_f32_dist_cb, head + (self._ar, self._ag, None, ci(self.world), vp(st.cuda_stream))
+            fn = L.tsqr_mi_qr_f32_dist_cb_loop if loop else L.tsqr_mi_qr_f32_dist_cb
+            args = head + (self._ar, self._ag, None, ci(self.world), vp(st.cuda_stream))
 
-        def call():
+        def call(k=None):
             self._cb_error = None
-            rc = fn(*args)
+            rc = fn(ci(int(k if k is not None else 1)), *args) if loop else fn(*args)
             if self._cb_error is not None:
                 raise self._cb_error
             if rc < 0:
@@ -225,6 +246,9 @@ class RowPartitionedQR:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n, self.m_local = n, m_local
         self.transport = "none"
+        # every rank must hold at least one row: a rank that bailed out alone would leave the others waiting in the first exchange
+        # (include/tsqr_mi.h) -- so the check is collective and every rank raises together
+        self._require_rows(m_local)
         if backend is not None:
             self.backend = backend
             self.transport = "test-double"
@@ -242,21 +266,48 @@ class RowPartitionedQR:
         self.transport = "rccl" if raw is not None else "torch.distributed callbacks"
         self.backend = HipBackend(mode, m_local, n, self.world, comm=raw, collectives=TorchCollectives(group))
 
+    def _require_rows(self, m_local):
+        """Collective: raises ValueError on EVERY rank when any rank's block is empty (or n == 0)."""
+        least = min(int(m_local), int(self.n))
+        if self.world > 1:
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            t = torch.tensor([least], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            least = int(t.item())
+        if least < 1:
+            raise ValueError("row-partitioned QR: every rank needs m_local >= 1 and n >= 1 (at least one rank passed an empty block)")
+
     def qr(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None):
         """q, a: column-major m_local x n blocks (tensors; q may alias a only with reorthogonalize... never for the first sweep);
-        r: (n, n) tensor receiving the column-major R, identical on every rank.  Blocking, collective.  Returns state_t."""
+        r: (n, n) tensor receiving the column-major R, identical on every rank.  Blocking, collective.  Returns state_t.
+        m_local: this call's block height when it differs from the constructor's (collective check that no rank passes 0; not taller
+        than the constructor's, which sized the work buffers)."""
+        if m_local is not None and m_local != self.m_local:
+            self._require_rows(m_local)
         m_local = self.m_local if m_local is None else m_local
-        if self.n == 0 or m_local == 0:
-            return bq.error_invalid_matrix_size
         return self.backend.qr_dist(q, ldq, r, self.n, a, lda, m_local, bool(reorthogonalize))
 
-    def bind(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None):
-        """The same call with its arguments marshalled once: returns a zero-argument callable (a C++ caller's loop body).  The
-        tensors and the current stream must stay alive and unchanged while it is in use."""
+    def bind(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None, loop=False):
+        """The same call with its arguments marshalled once: returns a zero-argument callable (a C++ caller's loop body); loop = True:
+        a callable taking a count k = k back-to-back calls from one C loop.  The tensors and the current stream must stay alive and
+        unchanged while it is in use."""
+        if m_local is not None and m_local != self.m_local:
+            self._require_rows(m_local)
         m_local = self.m_local if m_local is None else m_local
-        if hasattr(self.backend, "bind_dist") and self.n > 0 and m_local > 0:
-            return self.backend.bind_dist(q, ldq, r, self.n, a, lda, m_local, bool(reorthogonalize))
+        if hasattr(self.backend, "bind_dist"):
+            return self.backend.bind_dist(q, ldq, r, self.n, a, lda, m_local, bool(reorthogonalize), loop=loop)
+        if loop:
+            def run(k=1):
+                for _ in range(k):
+                    st = self.qr(q, ldq, r, a, lda, reorthogonalize, m_local)
+                    if st:
+                        return st
+                return 0
+            return run
         return lambda: self.qr(q, ldq, r, a, lda, reorthogonalize, m_local)
+
+    def bind_loop(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None):
+        return self.bind(q, ldq, r, a, lda, reorthogonalize, m_local, loop=True)
 
     @property
     def last_engine(self):
