@@ -17,6 +17,7 @@ _SO = os.path.join(_HERE, "libref_oracle.so")
 # position in mtk::qr::compute_mode (reference src/blockqr.hpp:12-23)
 FP32_NOTC = 2
 FP32_TC_COR = 3
+FP32_TC_NOCOR = 4
 
 
 def build(force=False):

@@ -2,7 +2,7 @@
  * oracle/ref_tsqr.c -- TEST INFRASTRUCTURE ONLY (not product code).
  *
  * CPU restatement, in plain C, of the algorithm of enp1s0/tsqr-gpu for the path
- *   mtk::qr::qr<fp32_notc|fp32_tc_cor, Reorth>()      (src/blockqr.hpp:142-175)
+ *   mtk::qr::qr<fp32_notc|fp32_tc_cor|fp32_tc_nocor, Reorth>()      (src/blockqr.hpp:142-175)
  * written from the source text of the reference.  Each function cites the
  * reference file:line it follows.
  *
@@ -13,7 +13,9 @@
  * enp1s0/gemm_core_cuh; URLs only in .gitmodules) plus closed-source cuBLAS SGEMM
  * and the Tensor-Core accumulator.  Assumptions made for those: sign(0)=+1,
  * k-ascending fp32 FMA inside the 16x16 matmul cores, plain fp32 sums for the
- * Tensor-Core accumulate.  What IS pinned, by formula, is checked in
+ * Tensor-Core accumulate; fp32_tc_nocor: an fp16 accumulator fragment is rounded to fp16
+ * once per mma_sync (K = 16), and cuBLAS SGEMM under CUBLAS_TENSOR_OP_MATH (src/blockqr.cu:64-68)
+ * rounds its inputs to fp16 and accumulates in fp32.  What IS pinned, by formula, is checked in
  * tests/test_oracle.py: batch-size rule, workspace sizes, error codes, metric
  * definitions, and agreement with LAPACK (scipy) up to column signs.
  *
@@ -28,6 +30,7 @@
 
 #define REF_FP32_NOTC   2   /* position in mtk::qr::compute_mode, src/blockqr.hpp:12-23 */
 #define REF_FP32_TC_COR 3
+#define REF_FP32_TC_NOCOR 4
 
 /* ---- fp16 round trip (cutf::type::cast<half>(float) then back), RNE, subnormals kept ---- */
 static inline float h16(float x) {
@@ -129,6 +132,26 @@ static void hx_tc_cor(float *X, const float *H, unsigned nc) {
 	memcpy(X, out, sizeof(float) * 32 * nc);
 }
 
+/* fp32_tc_nocor, src/tcqr32x16.cu:498-614.  H is an fp16 matrix (h_mat_t = half, :39).  X enters the product rounded to fp16
+ * (copy_32x16 into the half working memory, or already half when Q_T = half); one mma_sync per K = 16 half.
+ * acc_half = 0: fp32 accumulator fragments (R always, :510-511/:574; Q when Q_T = float, :499-560);
+ * acc_half = 1: fp16 accumulator fragments (Q when Q_T = half, :575: the tsqr working Q of this mode is half, src/tsqr.hpp:29):
+ *               the running value is rounded to fp16 after each mma_sync, and so is the stored result. */
+static void hx_tc_nocor(float *X, const float *H, unsigned nc, int acc_half) {
+	float out[32 * 32];
+	for (unsigned c = 0; c < nc; c++)
+		for (unsigned r = 0; r < 32; r++) {
+			float acc = 0.0f;
+			for (unsigned kb = 0; kb < 32; kb += 16) {
+				float s = 0.0f;
+				for (unsigned k = kb; k < kb + 16; k++) s += H[k * 32 + r] * h16(X[c * 32 + k]);
+				acc = acc_half ? h16(acc + s) : acc + s;
+			}
+			out[c * 32 + r] = acc;
+		}
+	memcpy(X, out, sizeof(float) * 32 * nc);
+}
+
 /*
  * One <=32 x n tile QR with explicit Householder matrices.
  * src/tcqr32x16.cu:1373-1469 (column loop), :117-137 / :228-274 (make_h),
@@ -136,7 +159,7 @@ static void hx_tc_cor(float *X, const float *H, unsigned nc) {
  * a: rows x n at a[ r + c*lda ];  q_out: rows x n (ldq);  r_out: n x n (ldr), stored verbatim.
  */
 static void tile_qr(int mode, float *q_out, size_t ldq, float *r_out, size_t ldr,
-                    const float *a, size_t lda, unsigned rows, unsigned n) {
+                    const float *a, size_t lda, unsigned rows, unsigned n, int q_half) {
 	float Rt[32 * 16], Qt[32 * 32], H[32 * 32], u[32];
 	for (unsigned c = 0; c < 16; c++)
 		for (unsigned r = 0; r < 32; r++)
@@ -166,6 +189,15 @@ static void tile_qr(int mode, float *q_out, size_t ldq, float *r_out, size_t ldr
 					const float acc = uh[y] * uh[x] + ul[y] * uh[x] + uh[y] * ul[x];
 					H[x * 32 + y] = -acc + ((x == y) ? 1.0f : 0.0f);
 				}
+		} else if (mode == REF_FP32_TC_NOCOR) {
+			/* src/tcqr32x16.cu:186-226: H in fp16; one outer product per 16 x 16 fragment with an fp16 accumulator:
+			 * H(y, x) = half(delta - half(half(u_y * alpha) * half(u_x))), alpha = 2 / |u|^2 */
+			const float alpha = 2.0f / norm2_u_1;
+			for (unsigned x = 0; x < 32; x++)
+				for (unsigned y = 0; y < 32; y++) {
+					const float p = h16(h16(u[y] * alpha) * h16(u[x]));
+					H[x * 32 + y] = h16(((x == y) ? 1.0f : 0.0f) - p);
+				}
 		} else {
 			/* src/tcqr32x16.cu:117-137 */
 			for (unsigned y = 0; y < 32; y++) {
@@ -177,8 +209,9 @@ static void tile_qr(int mode, float *q_out, size_t ldq, float *r_out, size_t ldr
 				}
 			}
 		}
-		if (mode == REF_FP32_TC_COR) { hx_tc_cor(Qt, H, 32); hx_tc_cor(Rt, H, 16); }
-		else                         { hx_notc(Qt, H, 32);   hx_notc(Rt, H, 16); }
+		if (mode == REF_FP32_TC_COR)        { hx_tc_cor(Qt, H, 32); hx_tc_cor(Rt, H, 16); }
+		else if (mode == REF_FP32_TC_NOCOR) { hx_tc_nocor(Qt, H, 32, q_half); hx_tc_nocor(Rt, H, 16, 0); }
+		else                                { hx_notc(Qt, H, 32);   hx_notc(Rt, H, 16); }
 	}
 	for (unsigned y = 0; y < n; y++)            /* s2g32x32_16x32_t_2w: Q_out(x, y) = Qt(y, x) */
 		for (unsigned x = 0; x < rows; x++) q_out[ldq * y + x] = Qt[32 * x + y];
@@ -187,9 +220,11 @@ static void tile_qr(int mode, float *q_out, size_t ldq, float *r_out, size_t ldr
 }
 
 /* AC(2n x n, ld) <- AC * B(n x n, ldb); both 16-row halves use the same B.
- * notc: src/tsqr.cu:143-204 / :591-656.  tc_cor: :330-412 / :790-876 (rescale 1024). */
+ * notc: src/tsqr.cu:143-204 / :591-656.  tc_cor: :330-412 / :790-876 (rescale 1024).
+ * tc_nocor: operands are the fp16 working Q (already half values); tree levels keep an fp16 accumulator and store half
+ * (:206-266, out_half = 1), layer 0 accumulates in fp32 and writes the user's float Q (:724-788, out_half = 0). */
 static void back_mul(int mode, float *out, size_t ldo, const float *ac, size_t ldac, unsigned rows,
-                     const float *b, size_t ldb, unsigned n) {
+                     const float *b, size_t ldb, unsigned n, int out_half) {
 	float tmp[32 * 16];
 	for (unsigned c = 0; c < n; c++)
 		for (unsigned r = 0; r < rows; r++) {
@@ -203,6 +238,9 @@ static void back_mul(int mode, float *out, size_t ldo, const float *ac, size_t l
 					c1 += al * bh; c2 += ah * bl; mn += ah * bh;
 				}
 				acc = (c1 + c2) * (1.0f / s) + mn;
+			} else if (mode == REF_FP32_TC_NOCOR) {
+				for (unsigned k = 0; k < n; k++) acc += h16(ac[r + k * ldac]) * h16(b[k + c * ldb]);
+				if (out_half) acc = h16(acc);
 			} else {
 				for (unsigned k = 0; k < n; k++) acc = fmaf(ac[r + k * ldac], b[k + c * ldb], acc);
 			}
@@ -218,7 +256,8 @@ static void back_mul(int mode, float *out, size_t ldo, const float *ac, size_t l
  */
 static void tsqr16(int mode, float *q, size_t ldq, float *r, size_t ldr, const float *a, size_t lda,
                    size_t m, unsigned n, float *wq, float *wr, unsigned *hl) {
-	if (m <= 32) { tile_qr(mode, q, ldq, r, ldr, a, lda, (unsigned)m, n); return; }   /* :1301-1309 */
+	if (m <= 32) { tile_qr(mode, q, ldq, r, ldr, a, lda, (unsigned)m, n, 0); return; }   /* :1301-1309: Q_T = the user's float */
+	const int qh = (mode == REF_FP32_TC_NOCOR);      /* the working Q of this mode is half: src/tsqr.hpp:29 */
 	const size_t L = ref_get_batch_size_log2(m), B = (size_t)1 << L;
 	float *wrs[2] = { wr, wr + (size_t)n * n * B };
 	const size_t ldrs[2] = { n * B, n * B / 2 };
@@ -227,7 +266,7 @@ static void tsqr16(int mode, float *q, size_t ldq, float *r, size_t ldr, const f
 	hl[B] = (unsigned)m;
 	#pragma omp parallel for schedule(static)
 	for (long i = 0; i < (long)B; i++)                                                /* :1102-1108 */
-		tile_qr(mode, wq + hl[i], m, wrs[0] + (size_t)n * i, ldrs[0], a + hl[i], lda, hl[i + 1] - hl[i], n);
+		tile_qr(mode, wq + hl[i], m, wrs[0] + (size_t)n * i, ldrs[0], a + hl[i], lda, hl[i + 1] - hl[i], n, qh);
 	for (size_t k = L - 1; k > 0 && L >= 1; k--) {                                    /* :1121-1159 */
 		const size_t lb = (size_t)1 << k;
 		const size_t off = 2 * (size_t)n * n * (B - ((size_t)1 << (k + 1))) + m * n;
@@ -236,11 +275,11 @@ static void tsqr16(int mode, float *q, size_t ldq, float *r, size_t ldr, const f
 		for (long j = 0; j < (long)lb; j++)
 			tile_qr(mode, wq + off + 2 * (size_t)n * j, 2 * n * lb,
 			        wrs[1 - idx] + (size_t)n * j, ldrs[1 - idx],
-			        wrs[idx] + 2 * (size_t)n * j, ldrs[idx], 2 * n, n);
+			        wrs[idx] + 2 * (size_t)n * j, ldrs[idx], 2 * n, n, qh);
 	}
 	{                                                                                 /* root :1164-1172 */
 		const size_t off = 2 * (size_t)n * n * (B - 2) + m * n;
-		tile_qr(mode, wq + off, 2 * n, r, ldr, wrs[1 - (L % 2)], ldrs[1 - (L % 2)], 2 * n, n);
+		tile_qr(mode, wq + off, 2 * n, r, ldr, wrs[1 - (L % 2)], ldrs[1 - (L % 2)], 2 * n, n, qh);
 	}
 	for (size_t k = 1; k < L; k++) {                                                  /* backward :1205-1230 */
 		const size_t lb = (size_t)1 << k;
@@ -250,21 +289,24 @@ static void tsqr16(int mode, float *q, size_t ldq, float *r, size_t ldr, const f
 		#pragma omp parallel for schedule(static)
 		for (long j = 0; j < (long)lb; j++)
 			back_mul(mode, ac + 2 * (size_t)n * j, ac_m, ac + 2 * (size_t)n * j, ac_m, 2 * n,
-			         bb + (size_t)n * j, ac_m / 2, n);
+			         bb + (size_t)n * j, ac_m / 2, n, 1);
 	}
 	#pragma omp parallel for schedule(static)
 	for (long i = 0; i < (long)B; i++)                                                /* layer 0 :1232-1260 */
-		back_mul(mode, q + hl[i], ldq, wq + hl[i], m, hl[i + 1] - hl[i], wq + m * n + (size_t)n * i, n * B, n);
+		back_mul(mode, q + hl[i], ldq, wq + hl[i], m, hl[i + 1] - hl[i], wq + m * n + (size_t)n * i, n * B, n, 0);
 }
 
-/* plain fp32 GEMMs standing in for cuBLAS default-math SGEMM (src/blockqr.cu:92-116, 230-332) */
+/* plain fp32 GEMMs standing in for cuBLAS default-math SGEMM (src/blockqr.cu:92-116, 230-332).  top = 1: the handle is in
+ * CUBLAS_TENSOR_OP_MATH (fp32_tc_nocor, src/blockqr.cu:64-68, 209-213): inputs rounded to fp16, fp32 accumulation (assumed). */
+static int g_top = 0;
+static inline float gin(float x) { return g_top ? h16(x) : x; }
 static void gemm_tn(float *c, size_t ldc, const float *a, size_t lda, const float *b, size_t ldb,
                     size_t mm, size_t nn, size_t kk) {          /* C(mm x nn) = A^T(mm x kk) B(kk x nn) */
 	#pragma omp parallel for collapse(2) schedule(static)
 	for (long j = 0; j < (long)nn; j++)
 		for (long i = 0; i < (long)mm; i++) {
 			float acc = 0.0f;
-			for (size_t k = 0; k < kk; k++) acc = fmaf(a[k + i * lda], b[k + j * ldb], acc);
+			for (size_t k = 0; k < kk; k++) acc = fmaf(gin(a[k + i * lda]), gin(b[k + j * ldb]), acc);
 			c[i + j * ldc] = acc;
 		}
 }
@@ -274,7 +316,7 @@ static void gemm_nn(float *c, size_t ldc, float alpha, const float *a, size_t ld
 	for (long i = 0; i < (long)mm; i++)
 		for (size_t j = 0; j < nn; j++) {
 			float acc = 0.0f;
-			for (size_t k = 0; k < kk; k++) acc = fmaf(a[i + k * lda], b[k + j * ldb], acc);
+			for (size_t k = 0; k < kk; k++) acc = fmaf(gin(a[i + k * lda]), gin(b[k + j * ldb]), acc);
 			c[i + j * ldc] = alpha * acc + (beta == 0.0f ? 0.0f : beta * c[i + j * ldc]);
 		}
 }
@@ -287,7 +329,8 @@ static void gemm_nn(float *c, size_t ldc, float alpha, const float *a, size_t ld
 int ref_qr_f32(int mode, int reorth, float *q, size_t ldq, float *r, size_t ldr, float *a, size_t lda,
                size_t m, size_t n) {
 	if (n > m || m == 0 || n == 0) return 1;
-	if (mode != REF_FP32_NOTC && mode != REF_FP32_TC_COR) return -1;
+	if (mode != REF_FP32_NOTC && mode != REF_FP32_TC_COR && mode != REF_FP32_TC_NOCOR) return -1;
+	g_top = (mode == REF_FP32_TC_NOCOR);             /* (one factorisation at a time: the oracle is not re-entrant) */
 	const size_t nb = 16;
 	float *wq = (float *)malloc(sizeof(float) * ref_working_q_size(m, n));
 	float *wr = (float *)malloc(sizeof(float) * ref_working_r_size(m, n));

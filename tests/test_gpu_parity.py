@@ -378,10 +378,13 @@ def test_dist_driver_single_rank(bq, oracle, torch_cuda, mode, policy, want_engi
 @pytest.mark.parametrize("m,n", [(128, 16), (20, 7), (4096, 64), (9211, 51), (65536, 64), (9000, 100)])
 @pytest.mark.parametrize("reorth", [False, True])
 def test_fp32_tc_nocor_mode(bq, oracle, torch_cuda, m, n, reorth):
-    """fp32_tc_nocor (reference src/tcqr32x16.cu:499-560: fp16 matrix-core products, no correction terms): fp16-level
-    accuracy by construction.  The oracle does not model this mode; the check is against fp64 LAPACK with the tolerance of
-    one fp16 rounding per operand (2^-11 = 4.9e-4): residual < 1e-3, ||Q^T Q - I||_F < 4e-3 * sqrt(n / 64 + 1),
-    sign-normalised R within 1e-3 -- and the R factor itself keeps fp32_tc_cor accuracy (it is computed the same way)."""
+    """fp32_tc_nocor (reference src/tcqr32x16.cu:186-226, 498-614, src/tsqr.cu:206-266, 724-788: fp16 matrix-core products, no
+    correction terms): fp16-level accuracy by construction.  Compared with (1) the oracle's restatement of that mode on the same
+    input -- the engine must be at least as accurate as the reference's arithmetic in both metrics and agree with its R and Q
+    within the sum of the two half-precision error levels -- and (2) fp64 LAPACK with the tolerance of one fp16 rounding per operand
+    (2^-11 = 4.9e-4): residual < 1e-3, ||Q^T Q - I||_F < 4e-3 * sqrt(n / 64 + 1), sign-normalised R within 1e-3.  The lower bound on
+    the residual says the uncorrected half-precision product really ran (fp32_tc_cor would give 5e-8); the R factor itself keeps
+    fp32_tc_cor accuracy for one sweep of one panel (it is computed the same way)."""
     a = oracle.uniform_matrix(m, n, seed=21)
     st, q, r = run_gpu(bq, torch_cuda, a, bq.compute_mode.fp32_tc_nocor, reorth, lda_pad=3, ldq_pad=1)
     assert st == bq.success_factorization
@@ -390,7 +393,18 @@ def test_fp32_tc_nocor_mode(bq, oracle, torch_cuda, m, n, reorth):
     assert 1e-6 < res < 1e-3, res                       # really the uncorrected half-precision product, not fp32_tc_cor
     assert orth < 4e-3 * np.sqrt(n / 64 + 1), orth
     q2, r2 = np.linalg.qr(a.astype(np.float64))
-    _, rn = oracle.sign_normalise(q, r)
-    _, r2n = oracle.sign_normalise(q2, r2)
+    qn, rn = oracle.sign_normalise(q, r)
+    q2n, r2n = oracle.sign_normalise(q2, r2)
     tol = 1e-3 if (reorth or n > 64) else 5e-6           # one sweep, one panel: R comes from the corrected Gram path alone
     assert np.abs(rn - r2n).max() / np.abs(r2n).max() < tol
+    # the reference's own arithmetic for this mode (oracle/ref_tsqr.c, REF_FP32_TC_NOCOR) on the same input
+    sto, qo, ro_ = oracle.qr(a, oracle.FP32_TC_NOCOR, reorth)
+    assert sto == 0
+    res_o, orth_o = oracle.residual(a, qo, ro_), oracle.orthogonality_fro(qo)
+    assert 1e-4 < res_o < 2e-2 and orth_o < 5e-2, (res_o, orth_o)      # the restatement is at fp16 level too (and not broken)
+    assert res <= res_o and orth <= orth_o, (res, res_o, orth, orth_o)  # never worse than the reference's mode
+    qon, ron = oracle.sign_normalise(qo, np.triu(ro_))
+    dr_o = np.abs(ron - r2n).max() / np.abs(r2n).max()                  # how far the reference's R is from the exact one ...
+    assert np.abs(rn - ron).max() / np.abs(ron).max() < dr_o + tol      # ... bounds how far ours may be from the reference's
+    dq_o = np.abs(qon - q2n).max()
+    assert np.abs(qn - qon).max() < dq_o + 2e-3 * np.abs(q2n).max() + 1e-4

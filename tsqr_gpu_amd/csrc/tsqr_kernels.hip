@@ -588,12 +588,16 @@ struct GramArgs {
 	double* part;                        // [gridDim.x][NTRI][256]  (tile, lane, reg) order of the MFMA accumulators
 	const unsigned* skip_status;         // optional: return at once when *skip_status != 0 (an earlier, speculatively enqueued
 	                                     // sweep this pass depends on was rejected; its successor Cholesky reports "rejected" too)
+	unsigned* ticket_zero;               // optional: arrival counter of the gram_reduce_chol_kernel launch that follows; zeroed here (the
+	                                     // work buffer is the caller's, uninitialised memory: every counted launch has a Gram launch,
+	                                     // or a counted launch that reset the counter, in front of it on the stream)
 };
 
 template <int NT>
 __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
+	if (a.ticket_zero && blockIdx.x == 0 && threadIdx.x == 0) *a.ticket_zero = 0u;
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
@@ -667,6 +671,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
+	if (a.ticket_zero && blockIdx.x == 0 && threadIdx.x == 0) *a.ticket_zero = 0u;
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
@@ -884,9 +889,166 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 	}
 }
 
+// In-kernel time stamps of the Cholesky step (diagnostic builds only: the selftest library is compiled with -DTSQR_CHOL_STAMPS, the
+// product library never is).  Lane 0 of every wave notes the shader clock (s_memtime) in LDS; the kernel dumps the table at its end.
+#ifdef TSQR_CHOL_STAMPS
+__device__ unsigned long long* g_chol_stamp_out = nullptr;           // [4 waves][CHOL_NSTAMP] + [4] s_memrealtime pairs
+constexpr int CHOL_NSTAMP = 160;
+__shared__ unsigned long long chol_stamp_lds[4 * CHOL_NSTAMP];
+#define CHOL_STAMP(slot) do { if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHOL_STAMP(slot) do {} while (0)
+#endif
+
+// rank-4 update of the register rows LO .. HI-1 (whole groups of four: LO, HI multiples of 4) of one wave with the four published rows
+// of a group (rr: [4][64] in LDS).  KK (the 16-row block, compile time) fixes which register rows still exist, so the code is free of
+// branches: all LDS reads of a call are independent of its arithmetic and can be issued back to back (a join between two loads makes
+// the compiler wait for the first: the round-2 form took 18-30 cycles per FMA here, tools/chol_stamps.py).  The four rows of a
+// register group are consecutive rows of the matrix: R[K0+u][i .. i+3] are two 16-byte LDS broadcasts.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <int LO, int HI, int KK, bool WITH_M>
+__device__ __forceinline__ void chol_update_slots(double (&g)[16], double (&mm)[16], const double* rr, const double (&rkj)[4], const double (&mkc)[4], int w) {
+	constexpr int NLIVE = 16 - 4 * KK;
+	constexpr int H = HI < NLIVE ? HI : NLIVE;
+	static_assert(LO % 4 == 0 && HI % 4 == 0, "whole register groups");
+	if constexpr (LO < H) {
+		f64x2 ra[(H - LO) / 4][4][2];
+#pragma unroll
+		for (int sg = LO / 4; sg < H / 4; sg++)
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const double* p = rr + u * 64 + 16 * (KK + sg) + 4 * w;
+				ra[sg - LO / 4][u][0] = *reinterpret_cast<const f64x2*>(p);
+				ra[sg - LO / 4][u][1] = *reinterpret_cast<const f64x2*>(p + 2);
+			}
+#pragma unroll
+		for (int s = LO; s < H; s++) {
+			double acc_g = g[s], acc_m = mm[s];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const double rki = ra[(s - LO) >> 2][u][(s & 3) >> 1][s & 1];     // R[K0+u][i]
+				acc_g = fma(-rki, rkj[u], acc_g);
+				if constexpr (WITH_M) acc_m = fma(-rki, mkc[u], acc_m);
+			}
+			g[s] = acc_g;
+			if constexpr (WITH_M) mm[s] = acc_m;
+		}
+	}
+}
+
+__device__ __forceinline__ double rsq_newton(double p) {     // v_rsq_f64 (~2^-23) + one Newton step (~2^-45)
+	const double y = __builtin_amdgcn_rsq(p);
+	return fma(0.5 * y, fma(-p * y, y, 1.0), y);
+}
+
+// chol_group2: the same elimination step with a shorter critical path (round 3).  Three changes against chol_group:
+//  * the owner first makes the 4 x 4 diagonal block of its group wave-uniform (ten lane reads, issued back to back) and factors it in
+//    uniform arithmetic: the chain pivot -> rsqrt -> Newton -> row scaling -> next pivot no longer passes through a lane read (VALU ->
+//    SGPR -> VALU) twice per pivot and pair; the four rows of R and of M are then formed for all 64 columns by the 4 x 4 forward
+//    substitution with those uniform multipliers -- independent work that fills the latency gaps of the chain;
+//  * look-ahead: after the barrier the NEXT owner updates only the four rows of its own group, factors and publishes them; the rest
+//    of that update (its rows 4..) is applied after ITS barrier, together with the update of its own group -- off the path, like
+//    every other wave's updates and the verdict bookkeeping (a full 16-row update is ~130 fp64 FMAs = ~1000 cycles of issue: in
+//    chol_group the next owner paid them before it could start);
+//  * the published rows therefore live in THREE rotating LDS buffers: a group's rows are still read (by the previous owner's
+//    deferred update) while the next owner publishes.
+// The arithmetic per entry is the same sequence of fma / multiplications as in chol_group (same results).
+// Rrow / Mrow: [3][4][64] doubles.  deferred: this wave still owes its rows 4.. the update of the group before the current one.
+template <int KK, int U>
+__device__ __forceinline__ void chol_group2(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* Zf, double* Zd,
+                                            double* pv, int w, int j, int n, double dgj, double& s_acc, bool& deferred) {
+	constexpr int K0 = 16 * KK + 4 * U;
+	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
+	constexpr int gi = 4 * KK + U;                       // group index 0..15
+	constexpr int bcur = gi % 3, bprev = (gi + 2) % 3;
+	double* rr = Rrow + bcur * 256;                      // [4][64]
+	double* mr = Mrow + bcur * 256;
+	CHOL_STAMP(8 + 8 * gi + 0);
+	if (w == U) {
+		// the 4 x 4 diagonal block, wave-uniform (row u of the group is register u; column K0+v is lane K0+v)
+		const double a00 = bcast_lane_f64(g[0], K0), a01 = bcast_lane_f64(g[0], K0 + 1), a02 = bcast_lane_f64(g[0], K0 + 2), a03 = bcast_lane_f64(g[0], K0 + 3);
+		const double a11 = bcast_lane_f64(g[1], K0 + 1), a12 = bcast_lane_f64(g[1], K0 + 2), a13 = bcast_lane_f64(g[1], K0 + 3);
+		const double a22 = bcast_lane_f64(g[2], K0 + 2), a23 = bcast_lane_f64(g[2], K0 + 3);
+		const double a33 = bcast_lane_f64(g[3], K0 + 3);
+		CHOL_STAMP(8 + 8 * gi + 1);
+		const double p0 = (a00 > 0.0) ? a00 : 1.0;       // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
+		const double y0 = rsq_newton(p0);
+		const double l01 = a01 * y0, l02 = a02 * y0, l03 = a03 * y0;
+		const double d1 = fma(-l01, l01, a11);
+		const double p1 = (d1 > 0.0) ? d1 : 1.0;
+		const double y1 = rsq_newton(p1);
+		const double l12 = fma(-l01, l02, a12) * y1, l13 = fma(-l01, l03, a13) * y1;
+		const double d2 = fma(-l12, l12, fma(-l02, l02, a22));
+		const double p2 = (d2 > 0.0) ? d2 : 1.0;
+		const double y2 = rsq_newton(p2);
+		const double l23 = fma(-l12, l13, fma(-l02, l03, a23)) * y2;
+		const double d3 = fma(-l23, l23, fma(-l13, l13, fma(-l03, l03, a33)));
+		const double p3 = (d3 > 0.0) ? d3 : 1.0;
+		const double y3 = rsq_newton(p3);
+		// rows of R and M for every column: forward substitution with the uniform multipliers
+		const double r0 = g[0] * y0, m0 = mm[0] * y0;
+		const double r1 = fma(-l01, r0, g[1]) * y1, m1 = fma(-l01, m0, mm[1]) * y1;
+		const double r2 = fma(-l12, r1, fma(-l02, r0, g[2])) * y2, m2 = fma(-l12, m1, fma(-l02, m0, mm[2])) * y2;
+		const double r3 = fma(-l23, r2, fma(-l13, r1, fma(-l03, r0, g[3]))) * y3, m3 = fma(-l23, m2, fma(-l13, m1, fma(-l03, m0, mm[3]))) * y3;
+		const double rv[4] = {r0, r1, r2, r3}, mv[4] = {m0, m1, m2, m3}, pvv[4] = {p0, p1, p2, p3}, yv[4] = {y0, y1, y2, y3}, dv[4] = {a00, d1, d2, d3};
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int K = K0 + u;
+			const bool live = K < n;
+			rr[u * 64 + j] = !live ? 0.0 : ((j > K) ? rv[u] : ((j == K) ? pvv[u] * yv[u] : 0.0));
+			mr[u * 64 + j] = live ? mv[u] : 0.0;
+			if (j == 0 && live) pv[K] = dv[u];
+		}
+		CHOL_STAMP(8 + 8 * gi + 2);
+	}
+	CHOL_STAMP(8 + 8 * gi + 3);
+	__syncthreads();
+	CHOL_STAMP(8 + 8 * gi + 4);
+	double rkj[4], mkc[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) { rkj[u] = rr[u * 64 + j]; mkc[u] = mr[u * 64 + j]; }
+	const bool next_exists = K0 + 4 < n;
+	if (next_exists && w == ((U + 1) & 3)) {
+		// next owner: only the four rows of its own group now (slots 0..3; after the last group of a 16-row block they are slots 4..7,
+		// which the rotation at the end of the block moves to 0..3); its rows 4.. (in the numbering after that rotation) follow
+		// after the next barrier
+		if constexpr (U < 3) chol_update_slots<0, 4, KK, true>(g, mm, rr, rkj, mkc, w);
+		else chol_update_slots<4, 8, KK, true>(g, mm, rr, rkj, mkc, w);
+		deferred = true;
+		CHOL_STAMP(8 + 8 * gi + 5);
+		return;
+	}
+	if (w == U && deferred) {
+		// this group's owner: first the update it still owes from the group before (those rows sit in the third buffer: the next
+		// owner publishes into the one after)
+		const double* rp = Rrow + bprev * 256;
+		const double* mp = Mrow + bprev * 256;
+		double rkp[4], mkp[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { rkp[u] = rp[u * 64 + j]; mkp[u] = mp[u * 64 + j]; }
+		chol_update_slots<4, 16, KK, true>(g, mm, rp, rkp, mkp, w);
+		deferred = false;
+	}
+	if (w == ((U + 3) & 3)) {                            // the previous owner: neither the owner nor the next one
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int K = K0 + u;
+			if (K < n) {
+				Rf[K * 65 + j] = (float)rkj[u];
+				Zf[K * 65 + j] = (j <= K) ? (float)mkc[u] : 0.0f;                    // Z[j][K] = M[K][j]
+				Zd[K * 65 + j] = (j <= K) ? mkc[u] : 0.0;                            // (fp64 image, read on by chol_wide_kernel)
+				if (j <= K) s_acc = fma(dgj * mkc[u], mkc[u], s_acc);                // sum of g_jj * Z[j][K]^2
+			}
+		}
+	}
+	if (w <= U) chol_update_slots<4, 16, KK, true>(g, mm, rr, rkj, mkc, w);   // (slots 0..3 of waves <= U are finished rows)
+	else chol_update_slots<0, 16, KK, true>(g, mm, rr, rkj, mkc, w);
+	CHOL_STAMP(8 + 8 * gi + 5);
+}
+
 // LOADG: functor e -> G tile entry e (accumulator order); host_status: optional device-visible alias of pinned host memory
 // that receives the three status words as well (the host then needs no copy operation to read them).
-template <class LOADG>
+template <bool V2 = false, class LOADG>
 __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
                                           float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double** gs_out = nullptr) {
@@ -895,10 +1057,14 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	__shared__ float Rf[64 * 65];                // R rows for the final store
 	__shared__ float Zf[64 * 65];                // rows of M = columns of Z for the final store (no global store inside the loop:
 	                                             // a workgroup barrier drains vmcnt, i.e. would wait for the store's round trip)
-	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
+	__shared__ double Rrow[3 * 256], Mrow[3 * 256], dg[64], pv[64];   // published rows: two (chol_group) / three (chol_group2) rotating buffers
 	const int t = threadIdx.x;
 	const int j = t & 63, w = t >> 6;
 	const int NP = 16 * NT;
+	CHOL_STAMP(0);
+#ifdef TSQR_CHOL_STAMPS
+	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
 	// issue the loads of G first (one value per thread and tile), then initialise LDS while they are in flight
 	double gv[10];
 	{
@@ -956,14 +1122,28 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	const double dgj = Gs[j * 65 + j];
 	double s_acc = 0.0;
 	__syncthreads();
-#pragma unroll 1
-	for (int kk = 0; kk < 4; kk++) {
-		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, Gs, pv, w, j, n, kk, dgj, s_acc); });
+	bool deferred = false;                               // (V2) this wave still owes its rows 4.. the previous group's update
+	CHOL_STAMP(1);
+	if constexpr (V2) {
+		// the 16 groups as straight-line code: the block index is a compile-time constant in every group (which register rows are
+		// alive, the LDS buffer of the group, the lanes of its diagonal block), and the rotation of the rows is a renaming
+		static_for<0, 4>([&](auto kc) {
+			constexpr int KK = decltype(kc)::value;
+			static_for<0, 4>([&](auto u) { chol_group2<KK, decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, Gs, pv, w, j, n, dgj, s_acc, deferred); });
 #pragma unroll
-		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
+			for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }
+		});
+	} else {
+#pragma unroll 1
+		for (int kk = 0; kk < 4; kk++) {
+			static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, Gs, pv, w, j, n, kk, dgj, s_acc); });
+#pragma unroll
+			for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
+		}
 	}
 	// scaled conditioning S = || D * inverse(R) ||_F^2 / n with D = diag(sqrt(g_jj)): 1 for orthogonal columns of any scaling,
 	// ~cond^2 of the column-scaled matrix otherwise.  An entry-wise error eps*sqrt(g_ii g_jj) of G perturbs Q^T Q by <= eps*n*S.
+	CHOL_STAMP(2);
 	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
 	__syncthreads();
 	if (j == 0) Rrow[w] = s_acc;
@@ -986,23 +1166,360 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 			status[1] = __builtin_bit_cast(unsigned, ratio);
 			status[2] = __builtin_bit_cast(unsigned, scond);
 			if (host_status) {
+				// (no fence: the host reads these words only after the completion word of a LATER kernel on the stream, or after a
+				// stream synchronisation -- a system-scope release here wrote back the whole L2 on the critical path of every call)
 				volatile unsigned* hs = host_status;
 				hs[1] = __builtin_bit_cast(unsigned, ratio);
 				hs[2] = __builtin_bit_cast(unsigned, scond);
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");    // system scope: words 1, 2 are visible before the verdict word
 				hs[0] = s0;
 			}
 		}
 	}
 	// Z out (fp32: column K of Z = row K of M; the padding rows were zeroed at the start) and R out (fp32, exact zeros below the
 	// diagonal) from their LDS images, coalesced
-	for (int K = w; K < n; K += 4)
-		if (j < NP) z[(size_t)K * NP + j] = Zf[K * 65 + j];
+	{
+		// (fixed trip counts: every LDS read of the two images is issued before the first store needs its value)
+		float zv[16], rv[16];
+		const int i = t & 63;
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			const int K = w + 4 * u;
+			zv[u] = Zf[min(K, 63) * 65 + j];
+			rv[u] = Rf[i * 65 + min(K, 63)];
+		}
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			const int K = w + 4 * u;
+			if (K < n && j < NP) z[(size_t)K * NP + j] = zv[u];
+			if (K < n && i < n) r[(size_t)K * ldr + i] = (i <= K) ? rv[u] : 0.0f;
+		}
+	}
+	CHOL_STAMP(3);
+#ifdef TSQR_CHOL_STAMPS
+	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 4] = __builtin_amdgcn_s_memrealtime();
+	__syncthreads();
+	if (g_chol_stamp_out)
+		for (int i = threadIdx.x; i < 4 * CHOL_NSTAMP; i += 256) g_chol_stamp_out[i] = chol_stamp_lds[i];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// chol_body3 (round 3): the same step -- R = chol(G), Z = inverse(R), verdict -- reorganised after in-kernel time stamps of chol_body
+// (tools/chol_stamps.py; profiles/r03_experiment_log.md): a group of four pivots cost ~2000-4700 cycles there, of which the pivot
+// chain is ~500; the rest was fp64 issue (a wave issues one v_fma_f64 per ~8-12 cycles, and every wave carried the rows of
+// M = R^-T through the elimination as well: 130 FMAs + 64 LDS reads per group and wave) in front of the next owner's chain.
+//   phase 1  elimination of G alone, groups of four pivots owned by the waves in turn:
+//            * the owner makes the 4 x 4 diagonal block of its group wave-uniform (ten lane reads issued back to back), factors it in
+//              uniform arithmetic and forms its four rows of R for all columns by the 4 x 4 forward substitution with those
+//              multipliers (independent work in the latency gaps of the pivot chain: rsqrt -> Newton -> scale -> next pivot);
+//            * look-ahead: after the barrier the NEXT owner updates only the four rows of its own group and starts; everything else
+//              (the other waves' updates, the owner's own remaining rows, the copy of the finished rows into the LDS image of R)
+//              is off the path.  The published rows rotate through three LDS buffers for that.
+//   phase 2  Z = inverse(R) by 16 x 16 blocks from the finished fp64 R: the four diagonal blocks by back substitution (one wave
+//            each), then the block diagonals above it, Z_ab = -Z_aa (sum_k R_ak Z_kb), the terms of a sum spread over the waves.
+//            ~n^3/6 FMAs in all instead of the ~n^3/2 that carrying M through the elimination costs in SIMD form.
+//   phase 3  verdict (pivot ratios, scaled conditioning S) and the fp32 images of R and Z, coalesced.
+// R and Z live in LDS column-major with leading dimension 65 (Rc[k * 65 + i] = R[i][k], Zc[k * 65 + i] = Z[i][k]; Zc is also what
+// chol_wide_kernel reads on).  Same interface and same status words as chol_body.
+// ---------------------------------------------------------------------------------------------
+template <int LO, int HI>
+__device__ __forceinline__ void chol3_update(double (&g)[16], const double* rr, const double (&rkj)[4], int w, int kk, int nlive) {
+#pragma unroll
+	for (int s = LO; s < HI; s++) {
+		if (s < nlive) {                                     // wave-uniform
+			const int i = 16 * (kk + (s >> 2)) + 4 * w + (s & 3);
+			double acc = g[s];
+#pragma unroll
+			for (int u = 0; u < 4; u++) acc = fma(-rr[u * 64 + i], rkj[u], acc);   // R[K0+u][i]: one word for every lane (LDS broadcast)
+			g[s] = acc;
+		}
+	}
+}
+
+template <int U>
+__device__ __forceinline__ void chol3_group(double (&g)[16], double* Rrow, double* Rc, double* pv, double* yinv,
+                                            int w, int j, int n, int kk, bool& deferred) {
+	const int K0 = 16 * kk + 4 * U;
+	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
+	const int gi = 4 * kk + U;                           // group index 0..15
+	double* rr = Rrow + (gi % 3) * 256;                  // this group's four rows: [4][64]
+	const int nlive = 16 - 4 * kk;                       // register rows that still exist
+	CHOL_STAMP(8 + 8 * gi + 0);
+	if (w == U) {
+		// the 4 x 4 diagonal block, wave-uniform (row u of the group is register u; column K0+v is lane K0+v)
+		const double a00 = bcast_lane_f64(g[0], K0), a01 = bcast_lane_f64(g[0], K0 + 1), a02 = bcast_lane_f64(g[0], K0 + 2), a03 = bcast_lane_f64(g[0], K0 + 3);
+		const double a11 = bcast_lane_f64(g[1], K0 + 1), a12 = bcast_lane_f64(g[1], K0 + 2), a13 = bcast_lane_f64(g[1], K0 + 3);
+		const double a22 = bcast_lane_f64(g[2], K0 + 2), a23 = bcast_lane_f64(g[2], K0 + 3);
+		const double a33 = bcast_lane_f64(g[3], K0 + 3);
+		CHOL_STAMP(8 + 8 * gi + 1);
+		const double p0 = (a00 > 0.0) ? a00 : 1.0;       // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
+		const double y0 = rsq_newton(p0);
+		const double r0 = g[0] * y0;
+		const double l01 = a01 * y0, l02 = a02 * y0, l03 = a03 * y0;
+		const double d1 = fma(-l01, l01, a11);
+		const double p1 = (d1 > 0.0) ? d1 : 1.0;
+		const double y1 = rsq_newton(p1);
+		const double r1 = fma(-l01, r0, g[1]) * y1;
+		const double l12 = fma(-l01, l02, a12) * y1, l13 = fma(-l01, l03, a13) * y1;
+		const double d2 = fma(-l12, l12, fma(-l02, l02, a22));
+		const double p2 = (d2 > 0.0) ? d2 : 1.0;
+		const double y2 = rsq_newton(p2);
+		const double r2 = fma(-l12, r1, fma(-l02, r0, g[2])) * y2;
+		const double l23 = fma(-l12, l13, fma(-l02, l03, a23)) * y2;
+		const double d3 = fma(-l23, l23, fma(-l13, l13, fma(-l03, l03, a33)));
+		const double p3 = (d3 > 0.0) ? d3 : 1.0;
+		const double y3 = rsq_newton(p3);
+		const double r3 = fma(-l23, r2, fma(-l13, r1, fma(-l03, r0, g[3]))) * y3;
+		// (entries left of the diagonal are rounding residue here; nobody reads them: the image of R below takes j >= K only.  Rows
+		// K >= n of a ragged panel are zero rows of G: their r is zero, their pivot 1.)
+		rr[0 * 64 + j] = r0; rr[1 * 64 + j] = r1; rr[2 * 64 + j] = r2; rr[3 * 64 + j] = r3;
+		if (j == 0) {
+			pv[K0] = a00; pv[K0 + 1] = d1; pv[K0 + 2] = d2; pv[K0 + 3] = d3;
+			yinv[K0] = y0; yinv[K0 + 1] = y1; yinv[K0 + 2] = y2; yinv[K0 + 3] = y3;      // 1 / r_kk
+		}
+		CHOL_STAMP(8 + 8 * gi + 2);
+	}
+	CHOL_STAMP(8 + 8 * gi + 3);
+	lds_barrier();                                       // (LDS only: the stores of finished results stay in flight)
+	CHOL_STAMP(8 + 8 * gi + 4);
+	double rkj[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) rkj[u] = rr[u * 64 + j];
+	if (K0 + 4 < n && w == ((U + 1) & 3)) {
+		// next owner: only the four rows of its own group now (slots 0..3; after the last group of a 16-row block they are slots 4..7,
+		// which the rotation at the end of the block moves to 0..3); its other rows follow after the next barrier
+		if constexpr (U < 3) chol3_update<0, 4>(g, rr, rkj, w, kk, nlive);
+		else chol3_update<4, 8>(g, rr, rkj, w, kk, nlive);
+		deferred = true;
+		CHOL_STAMP(8 + 8 * gi + 5);
+		return;
+	}
+	if (w == U && deferred) {
+		// this group's owner still owes its rows 4.. the update of the group before (whose rows sit in the third buffer)
+		const double* rp = Rrow + ((gi + 2) % 3) * 256;
+		double rkp[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) rkp[u] = rp[u * 64 + j];
+		chol3_update<4, 16>(g, rp, rkp, w, kk, nlive);
+		deferred = false;
+	}
+	if (w == ((U + 3) & 3)) {                            // the previous owner: the finished rows go to the column-major image of R
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int K = K0 + u;
+			Rc[j * 65 + K] = (j >= K && K < n) ? rkj[u] : 0.0;
+		}
+	}
+	if (w <= U) chol3_update<4, 16>(g, rr, rkj, w, kk, nlive);   // (slots 0..3 of waves <= U are finished rows)
+	else chol3_update<0, 16>(g, rr, rkj, w, kk, nlive);
+	CHOL_STAMP(8 + 8 * gi + 5);
+}
+
+// one 16 x 16 x 16 block term of phase 2 for the lane (c, rg): t[r] += sum_kk X[16 xa + 4 rg + r][16 xk + kk] * Y[16 xk + kk][16 yb + c]
+// (X, Y column-major, ld 65)
+__device__ __forceinline__ void chol3_block_term(double (&t)[4], const double* X, int xa, int xk, const double* Y, int yb, int c, int rg, double sign) {
+	const double* xp = X + (16 * xk) * 65 + 16 * xa + 4 * rg;
+	const double* yp = Y + (16 * yb + c) * 65 + 16 * xk;
+#pragma unroll
+	for (int kk = 0; kk < 16; kk++) {
+		const double y = sign * yp[kk];
+#pragma unroll
+		for (int r = 0; r < 4; r++) t[r] = fma(xp[kk * 65 + r], y, t[r]);
+	}
+}
+
+template <class LOADG>
+__device__ __forceinline__ void chol_body3(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
+                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
+                                           float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double** zimg_out = nullptr) {
+	__shared__ double Gs[64 * 65];               // symmetric G (assembly); afterwards Zc: Zc[k * 65 + i] = Z[i][k]
+	__shared__ double Rc[64 * 65];               // Rc[k * 65 + i] = R[i][k], zero below the diagonal
+	__shared__ double Tt[3 * 16 * 17];           // phase 2: partial block terms T of up to three waves ([wave][c][row])
+	__shared__ double Rrow[3 * 256], dg[64], pv[64], yinv[64], sred[4];
+	double* Zc = Gs;
+	if (zimg_out) *zimg_out = Zc;
+	const int t = threadIdx.x;
+	const int j = t & 63, w = t >> 6;
+	const int NP = 16 * NT;
+	CHOL_STAMP(0);
+#ifdef TSQR_CHOL_STAMPS
+	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+	// issue the loads of G first (one value per thread and tile), then initialise LDS while they are in flight
+	double gv[10];
+	{
+		int idx = 0;
+		for (int ti = 0; ti < 4; ti++)
+			for (int tj = ti; tj < 4; tj++) {
+				if (ti < NT && tj < NT) { gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = loadg(idx * 256 + t); idx++; }
+				else gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = 0.0;
+			}
+	}
+	if (NT < 4)                                          // with all ten tiles present every entry of Gs is written below
+		for (int i = t; i < 64 * 65; i += 256) Gs[i] = 0.0;
+	for (int e = n * NP + t; e < NP * NP; e += 256) z[e] = 0.0f;          // padding rows of Z
+	__syncthreads();
+	{
+		const int reg = t >> 6, l = t & 63;
+#pragma unroll
+		for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+			for (int tj = ti; tj < 4; tj++) {
+				if (ti < NT && tj < NT) {
+					// C/D layouts: f64 MFMA row = (lane>>4) + 4*reg, f32/bf16 MFMA row = 4*(lane>>4) + reg; col = lane&15
+					const int row = 16 * ti + (f32_layout ? 4 * (l >> 4) + reg : (l >> 4) + 4 * reg);
+					const int col = 16 * tj + (l & 15);
+					const double v = gv[ti * 4 + tj - (ti * (ti + 1)) / 2];
+					// a diagonal tile holds (i,j) and (j,i); in the bf16-split Gram matrix they can differ by an ulp (cross terms
+					// are added in opposite order), so only the upper-triangle owner writes both mirror positions
+					if (row <= col) {
+						Gs[row * 65 + col] = v;
+						Gs[col * 65 + row] = v;
+					}
+				}
+			}
+	}
+	__syncthreads();
+	if (shift_coef > 0.0) {                              // shifted Cholesky (Fukaya et al. 2020): G + s I, s = shift_coef * trace(G)
+		if (w == 0) {
+			double tr = (j < n) ? Gs[j * 65 + j] : 0.0;
+			for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+			if (j < n) Gs[j * 65 + j] += shift_coef * tr;
+		}
+		__syncthreads();
+	}
+	double g[16];
+#pragma unroll
+	for (int s = 0; s < 16; s++) g[s] = Gs[(16 * (s >> 2) + 4 * w + (s & 3)) * 65 + j];
+	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; yinv[t] = 1.0; }
+	__syncthreads();                                     // (every wave has its rows: Gs may be reused as Zc from here on)
+	// ---- phase 1: elimination ----
+	bool deferred = false;
+	CHOL_STAMP(1);
+#pragma unroll 1
+	for (int kk = 0; kk < 4; kk++) {
+		static_for<0, 4>([&](auto u) { chol3_group<decltype(u)::value>(g, Rrow, Rc, pv, yinv, w, j, n, kk, deferred); });
+#pragma unroll
+		for (int s = 0; s < 12; s++) g[s] = g[s + 4];    // the next 16-row block moves to slots 0..3
+	}
+	// ragged n: the rows of the groups that were skipped are zero rows of the image of R with a unit pivot (yinv = 1), so that phase 2
+	// needs no special cases
+	for (int K = 4 * ((n + 3) / 4) + w; K < 64; K += 4) Rc[j * 65 + K] = 0.0;
+	CHOL_STAMP(2);
+	lds_barrier();
+	// R out now (fp32, exact zeros below the diagonal): its stores overlap phase 2
 	{
 		const int i = t & 63;
 		if (i < n)
-			for (int jj = t >> 6; jj < n; jj += 4) r[(size_t)jj * ldr + i] = (i <= jj) ? Rf[i * 65 + jj] : 0.0f;
+			for (int jj = t >> 6; jj < n; jj += 4) r[(size_t)jj * ldr + i] = (float)Rc[jj * 65 + i];
 	}
+	// ---- phase 2: Z = inverse(R) by 16 x 16 blocks ----
+	const int c = j & 15, rg = j >> 4;
+	{
+		// diagonal blocks: wave a inverts R_aa by back substitution, lane c (of every lane row: four identical copies, lane row 0
+		// stores) owns column c:  z_i = (delta_ic - sum_{k > i} r_ik z_k) / r_ii
+		const int a = w;
+		double zc[16];
+#pragma unroll
+		for (int i = 15; i >= 0; i--) {
+			double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+			for (int k = i + 1; k < 16; k++) sacc = fma(-Rc[(16 * a + k) * 65 + 16 * a + i], zc[k], sacc);
+			zc[i] = sacc * yinv[16 * a + i];
+		}
+		if (rg == 0) {
+#pragma unroll
+			for (int i = 0; i < 16; i++) Zc[(16 * a + c) * 65 + 16 * a + i] = zc[i];
+		}
+		// the blocks below the block diagonal are zero
+		for (int b = 0; b < a; b++)
+			for (int i = rg; i < 16; i += 4) Zc[(16 * b + c) * 65 + 16 * a + i] = 0.0;
+	}
+	lds_barrier();
+#pragma unroll 1
+	for (int d = 1; d < 4; d++) {
+		// block diagonal d: Z_ab = -Z_aa T, T = sum_{k = a+1 .. b} R_ak Z_kb, b = a + d.  The d terms of every T are spread over the
+		// waves (unit u = pair * d + term -> wave u % 4, at most two rounds), partial T through LDS, then one wave per pair finishes.
+		const int npairs = 4 - d, nunits = npairs * d;
+		double tacc[4] = {0.0, 0.0, 0.0, 0.0};
+		for (int u = w; u < nunits; u += 4) {            // (nunits <= 4 except d = 2: 4 units; d = 3: 3 units; d = 1: 3 units)
+			const int pair = u / d, term = u % d;
+			const int a = pair, b = pair + d, k = a + 1 + term;
+			double tt[4] = {0.0, 0.0, 0.0, 0.0};
+			chol3_block_term(tt, Rc, a, k, Zc, b, c, rg, 1.0);
+			if (term == 0) {
+#pragma unroll
+				for (int r2 = 0; r2 < 4; r2++) tacc[r2] = tt[r2];
+			} else {
+#pragma unroll
+				for (int r2 = 0; r2 < 4; r2++) Tt[((pair * 2 + term - 1) * 16 + c) * 17 + 4 * rg + r2] = tt[r2];   // (d = 2: slots 0, 2; d = 3: slots 0, 1)
+			}
+		}
+		lds_barrier();
+		// the wave that computed term 0 of a pair owns the pair: add the other terms, exchange T through LDS (a lane needs the whole
+		// column c of T for the second product), finish
+		if (w < nunits && (w % d) == 0 && (w / d) < npairs) {
+			const int pair = w / d, a = pair, b = pair + d;
+			for (int term = 1; term < d; term++)
+#pragma unroll
+				for (int r2 = 0; r2 < 4; r2++) tacc[r2] += Tt[((pair * 2 + term - 1) * 16 + c) * 17 + 4 * rg + r2];
+			double* Tw = Tt + (d == 1 ? pair : pair * 2) * 16 * 17;   // exchange slot of the pair for the summed T (column c, 16 rows; for
+			                                                          // d >= 2 it held the pair's term 1, read above by the same lanes)
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int r2 = 0; r2 < 4; r2++) Tw[c * 17 + 4 * rg + r2] = tacc[r2];
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_wave_barrier();
+			double zo[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int k2 = 0; k2 < 16; k2++) {
+				const double tk = -Tw[c * 17 + k2];
+#pragma unroll
+				for (int r2 = 0; r2 < 4; r2++) zo[r2] = fma(Zc[(16 * a + k2) * 65 + 16 * a + 4 * rg + r2], tk, zo[r2]);
+			}
+#pragma unroll
+			for (int r2 = 0; r2 < 4; r2++) Zc[(16 * b + c) * 65 + 16 * a + 4 * rg + r2] = zo[r2];
+		}
+		lds_barrier();
+	}
+	CHOL_STAMP(6);
+	// ---- phase 3: verdict and the fp32 image of Z ----
+	// scaled conditioning S = || D * inverse(R) ||_F^2 / n with D = diag(sqrt(g_jj)); status words as in chol_body
+	double s_acc = 0.0;
+	for (int K = w; K < n; K += 4) {
+		const double zv = (j <= K) ? Zc[K * 65 + j] : 0.0;   // Z[j][K]
+		if (j < NP) z[(size_t)K * NP + j] = (float)zv;
+		if (j < n) s_acc = fma(dg[j] * zv, zv, s_acc);
+	}
+	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
+	if (j == 0) sred[w] = s_acc;
+	lds_barrier();
+	if (w == 0) {
+		const double d0 = dg[j], p0 = pv[j];
+		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
+		if (j < n && !(d0 >= min_diag)) ratio = 0.0f;    // (bf16-split level: column norms in the fp32 denormal product range)
+		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
+		if (j == 0) {
+			const float scond = (float)(((sred[0] + sred[1]) + (sred[2] + sred[3])) / (double)n);
+			const unsigned s0 = (ratio > min_ratio && scond <= max_scond) ? 0u : 1u;     // NaN compares false -> rejected
+			status[0] = s0;
+			status[1] = __builtin_bit_cast(unsigned, ratio);
+			status[2] = __builtin_bit_cast(unsigned, scond);
+			if (host_status) {
+				volatile unsigned* hs = host_status;
+				hs[1] = __builtin_bit_cast(unsigned, ratio);
+				hs[2] = __builtin_bit_cast(unsigned, scond);
+				hs[0] = s0;
+			}
+		}
+	}
+	CHOL_STAMP(3);
+#ifdef TSQR_CHOL_STAMPS
+	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 4] = __builtin_amdgcn_s_memrealtime();
+	__syncthreads();
+	if (g_chol_stamp_out)
+		for (int i = threadIdx.x; i < 4 * CHOL_NSTAMP; i += 256) g_chol_stamp_out[i] = chol_stamp_lds[i];
+#endif
 }
 
 struct CholArgs {
@@ -1022,6 +1539,8 @@ struct CholArgs {
 	float scond_floor;                   // bf16 level: S <= min(128, max(scond_floor, 0.12 sqrt(rows)))
 };
 
+// VAR: 0 chol_body (round 2), 1 chol_body with chol_group2, 2 chol_body3 (round 3: the product's)
+template <int VAR = 2>
 __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 	// prev_status: status word of an earlier factorisation this one depends on (speculatively enqueued second sweep): when that one
 	// was rejected this one reports "rejected" at once, so that everything enqueued behind it skips as well
@@ -1044,8 +1563,93 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 	} else {
 		shift = a.shift_coef * (rows * (double)a.n + (double)a.n * (double)(a.n + 1));
 	}
-	chol_body(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
-	          shift, min_diag);
+	if constexpr (VAR == 2)
+		chol_body3(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
+		           shift, min_diag);
+	else
+		chol_body<VAR == 1>(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
+		                    shift, min_diag);
+}
+
+// gram_reduce_chol_kernel: the reduction of the per-workgroup Gram partials AND the Cholesky step in one launch (single-GPU calls:
+// a row-partitioned call has an all-reduce between the two and keeps gram_reduce1_kernel + chol_kernel).  The grid is the
+// reduction's (16 entries per workgroup); every workgroup writes its 16 sums with write-through (sc1) stores, drains them and takes
+// a ticket with one agent-scope atomic add; the workgroup whose add returns the last ticket reads the summed tiles back with sc1
+// loads and runs chol_body -- the "last adder" hand-off of MI355X_MICROARCH.md (workgroup dispatch / inter-workgroup visibility:
+// sc1 stores + vmcnt(0) + barrier + one atomic add per workgroup; the last adder loads only after its add has returned, its other
+// waves behind a barrier).  Saves a kernel boundary and the Cholesky launch's own ramp (~3 us of the 2^20 x 64 call).
+struct ReduceCholArgs {
+	CholArgs ch;                         // ch.gsum: summed tiles (written here, then read by the last workgroup)
+	const double* part; int nparts; int nelem;
+	unsigned* ticket;                    // arrival counter: zero at launch (GramArgs::ticket_zero), reset to zero by the last workgroup
+};
+template <int VAR = 2>
+__global__ __launch_bounds__(256) void gram_reduce_chol_kernel(const ReduceCholArgs a) {
+	if (a.ch.prev_status && a.ch.prev_status[0] != 0) {      // (uniform over the grid: nobody takes a ticket)
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			a.ch.status[0] = 1u; a.ch.status[1] = 0u; a.ch.status[2] = 0u;
+			if (a.ch.host_status) { volatile unsigned* hs = a.ch.host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
+		}
+		return;
+	}
+	double* gout = const_cast<double*>(a.ch.gsum);
+	const int nelem = a.nelem, nparts = a.nparts;
+	const double* __restrict__ part = a.part;
+	if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&gout[nelem], a.ch.rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__shared__ double red[16][17];
+	__shared__ unsigned last_wg;
+	const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
+	const int el = blockIdx.x * 16 + e;
+	double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+	if (el < nelem) {                                        // (same partition and summation order as gram_reduce1_kernel)
+		double v[32];
+#pragma unroll
+		for (int u = 0; u < 32; u++) {
+			const int b = sg + 16 * u;
+			v[u] = part_load(&part[(size_t)min(b, nparts - 1) * nelem + el]);
+		}
+#pragma unroll
+		for (int u = 0; u < 32; u++)
+			if (sg + 16 * u >= nparts) v[u] = 0.0;
+#pragma unroll
+		for (int i = 0; i < 8; i++) { s0 += v[4 * i]; s1 += v[4 * i + 1]; s2 += v[4 * i + 2]; s3 += v[4 * i + 3]; }
+		for (int b = sg + 512; b < nparts; b += 16) s0 += part_load(&part[(size_t)b * nelem + el]);
+	}
+	red[sg][e] = (s0 + s1) + (s2 + s3);
+	__syncthreads();
+	if (sg == 0 && el < nelem) {
+		double v[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) v[k] = red[k][e];
+		const double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+		                   (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+		__hip_atomic_store(&gout[el], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1)
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its stores ...
+	__syncthreads();                                         // ... before the one lane that signals for the workgroup
+	if (threadIdx.x == 0) {
+		const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned last = (old == gridDim.x - 1) ? 1u : 0u;
+		if (last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next counted launch
+		last_wg = last;
+	}
+	__syncthreads();                                         // the last adder's other waves load behind this barrier
+	if (!last_wg) return;
+	const CholArgs& c = a.ch;
+	float min_ratio = 0.0f, max_scond = INFINITY;
+	double min_diag = 0.0, shift = 0.0;
+	if (c.level == 2) {
+		min_ratio = 0.03125f;
+		max_scond = fminf(128.0f, fmaxf(c.scond_floor, 0.12f * sqrtf((float)c.rows)));
+		min_diag = c.rows * 0x1p-90;
+	} else if (c.level == 1) {
+		min_ratio = 9.094947017729282e-13f;              // 2^-40
+	} else {
+		shift = c.shift_coef * (c.rows * (double)c.n + (double)c.n * (double)(c.n + 1));
+	}
+	auto loadg = [&](int e2) { return __hip_atomic_load(&c.gsum[e2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // sc1: L2, never a stale L1 line
+	if constexpr (VAR == 2) chol_body3(c.r, c.ldr, c.z, c.status, c.host_status, loadg, c.n, c.NT, c.level == 2 ? 1 : 0, min_ratio, max_scond, shift, min_diag);
+	else chol_body<VAR == 1>(c.r, c.ldr, c.z, c.status, c.host_status, loadg, c.n, c.NT, c.level == 2 ? 1 : 0, min_ratio, max_scond, shift, min_diag);
 }
 
 // ---------------------------------------------------------------------------------------------

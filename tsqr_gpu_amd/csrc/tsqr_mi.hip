@@ -59,6 +59,8 @@ struct Settings {
 	const int auto_sweep2 = env_int("TSQR_MI_AUTO_SWEEP2", 1);   // n <= 16 without reorth: second sweep when the first one is ill conditioned
 	const int fold_tree = env_int("TSQR_MI_FOLD_TREE", 1);       // Householder engine, 64-column panels: collapsed R-stack tree (fold_tree_kernel)
 	const int fold_cor = env_int("TSQR_MI_FOLD_COR", 1);         // Householder engine, fp32_tc_cor: error-corrected bf16x3 MFMA block reflectors
+	const int chol_var = env_int("TSQR_MI_CHOL_VAR", 0);         // Cholesky step: 0 round-2 chol_body, 1 + chol_group2, 2 chol_body3
+	const int merge_chol = env_int("TSQR_MI_MERGE_CHOL", 1);     // single-GPU calls: Gram reduction + Cholesky in one launch (gram_reduce_chol_kernel)
 };
 Settings g_set;
 std::atomic<unsigned> g_seq{0};                        // sequence numbers of the completion flags (any thread)
@@ -264,6 +266,9 @@ struct Ctx {
 	double* gramq_part = nullptr;                        // non-null: apply launches write per-workgroup Gram partials of their output there
 	int gramq_cap = 0, gramq_nparts = 0;
 	bool gramq_ready = false;                            // the next bf16-level Gram request can skip its pass (partials are in place)
+	const double* pend_part = nullptr;                   // per-workgroup Gram partials whose reduction is still to be enqueued: the next
+	int pend_nparts = 0, pend_nelem = 0;                 // chol_from_g sums them and factors in ONE launch (gram_reduce_chol_kernel)
+	unsigned* ticket() const { return reinterpret_cast<unsigned*>(wq + L.status) + 15; }   // (word 15 of status slot 0: slots use words 0..2)
 	Comm comm;
 	bool fold_cor = false;                               // Householder engine: block reflectors on the error-corrected bf16x3 MFMA (fp32_tc_cor)
 	double rows_global = 0.0;                            // host's view of the global row count (the device thresholds of a row-partitioned
@@ -466,13 +471,16 @@ template <int NT> void launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool 
 
 // Gram matrix of src (m x n) in MFMA-accumulator order -> c.gsum() (ntri*256 doubles + the local row count behind them), summed
 // over the ranks of a row-partitioned call.  bf16 = true: bf16x3-split MFMA (memory-bound, f32 C/D layout), false: fp64 MFMA.
-int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16) {
+// reduce_now = false (single-GPU ladder): the partials stay pending and the NEXT chol_from_g sums and factors them in one launch.
+int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16, bool reduce_now = true) {
 	const GramPlan g = gram_plan(m, n);
 	const int NT = (int)(np_of(n) / 16);
 	tsqrmi::GramArgs a{};
 	a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
 	a.part = reinterpret_cast<double*>(c.wr);
 	a.skip_status = c.prev_slot >= 0 ? c.status_dev(c.prev_slot) : nullptr;
+	a.ticket_zero = c.ticket();
+	c.pend_part = nullptr;
 	int nparts = g.nblocks;                              // workgroups that wrote a partial
 	if (bf16 && c.gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		c.gramq_ready = false;
@@ -488,6 +496,10 @@ int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16) {
 	}
 	HIPCHK(hipGetLastError());
 	const int nelem = g.ntri * 256;
+	if (!reduce_now && !c.comm.active() && g_set.merge_chol) {
+		c.pend_part = a.part; c.pend_nparts = nparts; c.pend_nelem = nelem;
+		return 0;
+	}
 	{
 		ProfScope ps(KC_CHOL, c.st);
 		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), a.part, nparts, nelem, (double)m);
@@ -515,9 +527,21 @@ int chol_from_g(Ctx& c, float* r, size_t ldr, size_t n, int level) {
 	a.rows = c.rows_global;
 	a.shift_coef = (level == 3) ? 11.0 * 1.1102230246251565e-16 : 0.0;
 	a.n = (int)n; a.NT = NT; a.level = level; a.scond_floor = g_set.bf16_scond_floor;
-	{
+	if (c.pend_part) {
+		// the Gram pass just enqueued left its partials unreduced: reduction + Cholesky in one launch (last-arriving workgroup factors)
+		tsqrmi::ReduceCholArgs ra{};
+		ra.ch = a; ra.part = c.pend_part; ra.nparts = c.pend_nparts; ra.nelem = c.pend_nelem; ra.ticket = c.ticket();
+		c.pend_part = nullptr;
 		ProfScope ps(KC_CHOL, c.st);
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, a);
+		const dim3 grid((ra.nelem + 15) / 16);
+		if (g_set.chol_var == 2) hipLaunchKernelGGL(tsqrmi::gram_reduce_chol_kernel<2>, grid, dim3(256), 0, c.st, ra);
+		else if (g_set.chol_var == 1) hipLaunchKernelGGL(tsqrmi::gram_reduce_chol_kernel<1>, grid, dim3(256), 0, c.st, ra);
+		else hipLaunchKernelGGL(tsqrmi::gram_reduce_chol_kernel<0>, grid, dim3(256), 0, c.st, ra);
+	} else {
+		ProfScope ps(KC_CHOL, c.st);
+		if (g_set.chol_var == 2) hipLaunchKernelGGL(tsqrmi::chol_kernel<2>, dim3(1), dim3(256), 0, c.st, a);
+		else if (g_set.chol_var == 1) hipLaunchKernelGGL(tsqrmi::chol_kernel<1>, dim3(1), dim3(256), 0, c.st, a);
+		else hipLaunchKernelGGL(tsqrmi::chol_kernel<0>, dim3(1), dim3(256), 0, c.st, a);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -658,7 +682,7 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 	const bool direct_shift = (r_engine == R_SHIFT_DIRECT);
 	if (direct_shift) r_engine = 0;
 	for (int e = r_engine; e >= 1; e--) {                // 2: bf16-split Gram, 1: fp64 Gram; with check_now a rejected level escalates
-		rc = gram_g(c, ap, lda, m, cc, e == 2);
+		rc = gram_g(c, ap, lda, m, cc, e == 2, /*reduce_now=*/false);
 		if (rc) return rc;
 		rc = chol_from_g(c, rpp, ldr, cc, e);
 		if (rc) return rc;
@@ -690,7 +714,7 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 		if (status == 0) {
 			rc = apply_rinv(c, engine, qp, ldq, ap, lda, r1, cc, m, cc, /*z_ready=*/true);
 			if (rc) return rc;
-			rc = gram_g(c, qp, ldq, m, cc, /*bf16=*/false);
+			rc = gram_g(c, qp, ldq, m, cc, /*bf16=*/false, /*reduce_now=*/false);
 			if (rc) return rc;
 			rc = chol_from_g(c, r2, cc, cc, 1);
 			if (rc) return rc;
