@@ -40,23 +40,8 @@ def pack_tiles(g, n, f32_layout):
     return np.concatenate(out)
 
 
-VAR = 0             # module switch set by the `variant` fixture: the selftest entry runs chol_kernel<reps / 1000>
-VARIANTS = ["chol_body", "chol_body+chol_group2", "chol_body3"]
-
-
-@pytest.fixture(params=VARIANTS, autouse=True)
-def variant(request):
-    """every test runs against the three forms of the step: round 2's, round 2's with the uniform-block / look-ahead elimination,
-    and round 3's (elimination of G alone + blocked triangular inverse: what the product launches)"""
-    global VAR
-    VAR = VARIANTS.index(request.param)
-    yield request.param
-    VAR = 0
-
-
 def run(st, g, n, level=1, rows=1 << 20, ldr=None, reps=0):
     """level 2 packs the tiles in the f32 accumulator layout, levels 1 / 3 in the f64 layout (what each Gram kernel writes)"""
-    reps += 1000 * VAR
     f32_layout = 1 if level == 2 else 0
     L, torch = st
     nt = (n + 15) // 16
@@ -152,5 +137,5 @@ def test_timing_report(st):
     g, _ = spd(64, 3.0, 1)
     for n in (16, 32, 48, 64):
         ms = run(st, g[:n, :n], n, level=2, reps=50)[5]
-        print("chol_kernel<%s> n=%d: %.2f us per launch (back to back)" % (VARIANTS[VAR], n, ms * 1e3))
+        print("chol_kernel n=%d: %.2f us per launch (back to back; diagnostic build with time stamps)" % (n, ms * 1e3))
     assert ms < 0.05

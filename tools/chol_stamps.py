@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-kernel time stamps of the Cholesky step (libtsqr_selftest.so is built with -DTSQR_CHOL_STAMPS): per-group breakdown in shader
-cycles for the owner wave, the next owner and the others.  usage: chol_stamps.py [n] [v2=1]"""
+cycles for the owner wave, the next owner and the others.  usage: chol_stamps.py [n]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,32 +8,26 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 import test_gpu_chol as tc
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-v2 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 L = ctypes.CDLL(os.path.join(tc.ROOT, "tsqr_gpu_amd", "csrc", "libtsqr_selftest.so"))
 L.tsqr_selftest_chol_stamps.restype = ctypes.c_int
 L.tsqr_selftest_chol_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
 g, _ = tc.spd(n, 3.0, 1)
 nt = (n + 15) // 16
 gs = torch.from_numpy(tc.pack_tiles(g, n, 1)).cuda()
 r = torch.zeros(n * n, device="cuda"); z = torch.zeros(256 * nt * nt, device="cuda"); st = torch.zeros(4, dtype=torch.int32, device="cuda")
 out = torch.zeros(4 * 160, dtype=torch.int64, device="cuda")
-rc = L.tsqr_selftest_chol_stamps(out.data_ptr(), r.data_ptr(), n, z.data_ptr(), st.data_ptr(), gs.data_ptr(), n, nt, 2, float(1 << 20), v2)
+rc = L.tsqr_selftest_chol_stamps(out.data_ptr(), r.data_ptr(), n, z.data_ptr(), st.data_ptr(), gs.data_ptr(), n, nt, 2, float(1 << 20))
 assert rc == 0, rc
 s = out.cpu().numpy().reshape(4, 160)
-t0 = s[:, 0].min()
 clk = (s[0, 3] - s[0, 0]) / max(1, (s[0, 4] - s[0, 5])) * 100.0      # MHz: shader cycles per 100 MHz tick
-print("variant %s n=%d: kernel body %d cycles (wave 0), clock ~%.0f MHz => %.2f us" % (["chol_body", "chol_group2", "chol_body3"][v2], n, s[0, 3] - s[0, 0], clk, (s[0, 3] - s[0, 0]) / clk))
-print("prologue (start -> first group) %d   groups %d   epilogue %d" % (s[0, 1] - s[0, 0], s[0, 2] - s[0, 1], s[0, 3] - s[0, 2]))
-if v2 == 2:
-    print("phase 1 %d  phase 2 (inverse) %d  phase 3 %d" % (s[0, 2] - s[0, 1], s[0, 6] - s[0, 2], s[0, 3] - s[0, 6]))
-if v2:
-    print("group: owner[entry->lanes read, chain+rows+publish] | barrier wait (owner / next owner / others) | next owner: 4-row update | others: after barrier -> end")
-    for gi in range((n + 3) // 4):
-        U = gi % 4; nxt = (U + 1) % 4; oth = (U + 2) % 4
-        b = 8 + 8 * gi
-        o = s[U]
-        print("g%02d owner w%d: %5d %5d | bar %5d %5d %5d | next w%d upd %5d | other w%d upd %5d | owner post %5d | period %5d" % (
-            gi, U, o[b + 1] - o[b], o[b + 2] - o[b + 1], o[b + 4] - o[b + 3], s[nxt][b + 4] - s[nxt][b + 3], s[oth][b + 4] - s[oth][b + 3],
-            nxt, s[nxt][b + 5] - s[nxt][b + 4], oth, s[oth][b + 5] - s[oth][b + 4], o[b + 5] - o[b + 4],
-            (s[U][b + 8] - s[U][b]) if gi + 1 < (n + 3) // 4 else 0))
+print("chol_kernel n=%d: kernel body %d cycles (wave 0), clock ~%.0f MHz => %.2f us" % (n, s[0, 3] - s[0, 0], clk, (s[0, 3] - s[0, 0]) / clk))
+print("prologue (start -> first group) %d   elimination %d   epilogue (verdict, images out) %d" % (s[0, 1] - s[0, 0], s[0, 2] - s[0, 1], s[0, 3] - s[0, 2]))
+print("group: owner section | barrier wait of the owner / of another wave | updates after the barrier (owner / another wave) | period")
+for gi in range((n + 3) // 4):
+    U = gi % 4; oth = (U + 2) % 4
+    b = 8 + 8 * gi
+    o, x = s[U], s[oth]
+    print("g%02d owner w%d: %5d | bar %5d %5d | upd %5d %5d | period %5d" % (
+        gi, U, o[b + 1] - o[b], o[b + 2] - o[b + 1], x[b + 2] - x[b + 1], o[b + 3] - o[b + 2], x[b + 3] - x[b + 2],
+        (o[b + 8] - o[b]) if gi + 1 < (n + 3) // 4 else 0))

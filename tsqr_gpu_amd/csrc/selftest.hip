@@ -66,14 +66,7 @@ extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* st
 	a.rows = rows; a.shift_coef = (level == 3) ? 11.0 * 1.1102230246251565e-16 : 0.0; a.n = n; a.NT = NT; a.level = level; a.scond_floor = 4.0f;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	// reps >= 1000: variant (reps / 1000) of the kernel -- 1: chol_group2, 2: chol_body3 -- with reps % 1000 timed launches
-	const int var = reps / 1000;
-	reps %= 1000;
-	auto launch = [&]() {
-		if (var == 2) hipLaunchKernelGGL(tsqrmi::chol_kernel<2>, dim3(1), dim3(256), 0, 0, a);
-		else if (var == 1) hipLaunchKernelGGL(tsqrmi::chol_kernel<1>, dim3(1), dim3(256), 0, 0, a);
-		else hipLaunchKernelGGL(tsqrmi::chol_kernel<0>, dim3(1), dim3(256), 0, 0, a);
-	};
+	auto launch = [&]() { hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a); };
 	launch();
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++) launch();
@@ -87,20 +80,16 @@ extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* st
 }
 
 
-// ---- in-kernel time stamps of chol_kernel<true> (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----
+// ---- in-kernel time stamps of chol_kernel (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----
 extern "C" int tsqr_selftest_chol_stamps(unsigned long long* out_dev, float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT,
-                                         int level, double rows, int v2) {
+                                         int level, double rows) {
 #ifdef TSQR_CHOL_STAMPS
 	tsqrmi::CholArgs a{};
 	a.r = r; a.ldr = ldr; a.z = z; a.status = status; a.host_status = nullptr; a.gsum = gsum; a.prev_status = nullptr; a.rows_dev = nullptr;
 	a.rows = rows; a.shift_coef = 0.0; a.n = n; a.NT = NT; a.level = level; a.scond_floor = 4.0f;
 	unsigned long long* null_out = nullptr;
 	hipMemcpyToSymbol(HIP_SYMBOL(tsqrmi::g_chol_stamp_out), &null_out, sizeof(null_out));
-	auto launch = [&]() {
-		if (v2 == 2) hipLaunchKernelGGL(tsqrmi::chol_kernel<2>, dim3(1), dim3(256), 0, 0, a);
-		else if (v2 == 1) hipLaunchKernelGGL(tsqrmi::chol_kernel<1>, dim3(1), dim3(256), 0, 0, a);
-		else hipLaunchKernelGGL(tsqrmi::chol_kernel<0>, dim3(1), dim3(256), 0, 0, a);
-	};
+	auto launch = [&]() { hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a); };
 	for (int i = 0; i < 20; i++) launch();               // warm: clocks, instruction cache
 	hipMemcpyToSymbol(HIP_SYMBOL(tsqrmi::g_chol_stamp_out), &out_dev, sizeof(out_dev));
 	launch();
@@ -109,298 +98,6 @@ extern "C" int tsqr_selftest_chol_stamps(unsigned long long* out_dev, float* r, 
 #else
 	return -1;
 #endif
-}
-
-// ---- copy kernel in the (c,q) chunk layout: the HBM ceiling of load_chunk + 16-B-per-lane stores ----
-template <int MODE>
-__global__ __launch_bounds__(256) void copy_cq_kernel(float* q, const float* a, size_t ld, size_t m, int nchunks, int cpw, int nwaves) {
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = blockIdx.x * 4 + wv;
-	if (gw >= nwaves) return;
-	const int c = lane & 15, qq = lane >> 4;
-	const int ch_end = min(nchunks, (gw + 1) * cpw);
-	for (int ch = gw * cpw; ch < ch_end; ch++) {
-		const size_t row0 = (size_t)ch * 64;
-		float p[4][16];
-		if (MODE == 0) {
-			tsqrmi::load_chunk<4>(p, a, ld, row0, m, 64, c, qq);
-		} else {   // MODE 1: 128-B lines per instruction: lane l -> column (l >> 3) + 8*g, rows 4*(l & 7) .. within 32-row halves
-#pragma unroll
-			for (int g = 0; g < 8; g++)
-#pragma unroll
-				for (int h = 0; h < 2; h++) {
-					const int col = 8 * g + (lane >> 3);
-					const tsqrmi::f32x4u v = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)col * ld + row0 + 32 * h + 4 * (lane & 7));
-					p[g >> 1][8 * (g & 1) + 4 * h + 0] = v[0]; p[g >> 1][8 * (g & 1) + 4 * h + 1] = v[1];
-					p[g >> 1][8 * (g & 1) + 4 * h + 2] = v[2]; p[g >> 1][8 * (g & 1) + 4 * h + 3] = v[3];
-				}
-		}
-		if (MODE == 0) {
-#pragma unroll
-			for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-				for (int rt = 0; rt < 4; rt++) {
-					tsqrmi::f32x4 v = {p[ct][4 * rt], p[ct][4 * rt + 1], p[ct][4 * rt + 2], p[ct][4 * rt + 3]};
-					*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)(16 * ct + c) * ld + row0 + 16 * rt + 4 * qq) = v;
-				}
-		} else {
-#pragma unroll
-			for (int g = 0; g < 8; g++)
-#pragma unroll
-				for (int h = 0; h < 2; h++) {
-					const int col = 8 * g + (lane >> 3);
-					tsqrmi::f32x4 v = {p[g >> 1][8 * (g & 1) + 4 * h + 0], p[g >> 1][8 * (g & 1) + 4 * h + 1],
-					                   p[g >> 1][8 * (g & 1) + 4 * h + 2], p[g >> 1][8 * (g & 1) + 4 * h + 3]};
-					*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + 32 * h + 4 * (lane & 7)) = v;
-				}
-		}
-	}
-}
-// read-only variants: MODE 0 (c,q) 64-B segments, MODE 1 full 128-B lines per instruction
-template <int MODE>
-__global__ __launch_bounds__(256) void read_cq_kernel(float* out, const float* a, size_t ld, size_t m, int nchunks, int cpw, int nwaves) {
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = blockIdx.x * 4 + wv;
-	if (gw >= nwaves) return;
-	const int c = lane & 15, qq = lane >> 4;
-	const int ch_end = min(nchunks, (gw + 1) * cpw);
-	float acc = 0.f;
-	for (int ch = gw * cpw; ch < ch_end; ch++) {
-		const size_t row0 = (size_t)ch * 64;
-		float p[4][16];
-		if (MODE == 0) {
-			tsqrmi::load_chunk<4>(p, a, ld, row0, m, 64, c, qq);
-		} else {
-#pragma unroll
-			for (int g = 0; g < 8; g++)
-#pragma unroll
-				for (int h = 0; h < 2; h++) {
-					const int col = 8 * g + (lane >> 3);
-					const tsqrmi::f32x4u v = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)col * ld + row0 + 32 * h + 4 * (lane & 7));
-					p[g >> 1][8 * (g & 1) + 4 * h + 0] = v[0]; p[g >> 1][8 * (g & 1) + 4 * h + 1] = v[1];
-					p[g >> 1][8 * (g & 1) + 4 * h + 2] = v[2]; p[g >> 1][8 * (g & 1) + 4 * h + 3] = v[3];
-				}
-		}
-#pragma unroll
-		for (int t = 0; t < 4; t++)
-#pragma unroll
-			for (int r = 0; r < 16; r++) acc += p[t][r];
-	}
-	if (acc == 123.456f) out[0] = acc;
-}
-// MODE 2: every wave instruction reads 1 KB contiguous of ONE column (lane l: rows 4l..4l+3); a workgroup covers a
-// 256-row x 64-column block, wave w takes columns w, w+4, ...
-__global__ __launch_bounds__(256) void read_linear_kernel(float* out, const float* a, size_t ld, size_t m, int nblocks_rows, int bpw) {
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	float acc = 0.f;
-	for (int b = blockIdx.x * bpw; b < min(nblocks_rows, (int)(blockIdx.x + 1) * bpw); b++) {
-		const size_t row0 = (size_t)b * 256;
-		tsqrmi::f32x4u v[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)(wv + 4 * k) * ld + row0 + 4 * lane);
-#pragma unroll
-		for (int k = 0; k < 16; k++) acc += v[k][0] + v[k][1] + v[k][2] + v[k][3];
-	}
-	if (acc == 123.456f) out[0] = acc;
-}
-__global__ void flush_kernel(float* big, size_t n) {
-	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) big[i] = 1.0f;
-}
-// cold timing: evict caches with a 1 GiB fill, then time ONE launch
-extern "C" float tsqr_selftest_read_cold(float* q, const float* a, size_t m, int mode, int waves, float* big, size_t nbig, int reps) {
-	const int nch = (int)(m / 64);
-	const int cpw = (nch + waves - 1) / waves;
-	const int nwaves = (nch + cpw - 1) / cpw;
-	hipEvent_t e0, e1;
-	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-	float tot = 0.f;
-	for (int it = 0; it < reps; it++) {
-		if (big) hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(256), 0, 0, big, nbig);
-		(void)hipEventRecord(e0, 0);
-		if (mode == 0) hipLaunchKernelGGL(read_cq_kernel<0>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
-		else if (mode == 1) hipLaunchKernelGGL(read_cq_kernel<1>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
-		else {
-			const int nb = (int)(m / 256); const int wgs = waves / 4; const int bpw = (nb + wgs - 1) / wgs;
-			hipLaunchKernelGGL(read_linear_kernel, dim3((nb + bpw - 1) / bpw), dim3(256), 0, 0, q, a, m, m, nb, bpw);
-		}
-		(void)hipEventRecord(e1, 0);
-		(void)hipEventSynchronize(e1);
-		float ms = 0.f;
-		(void)hipEventElapsedTime(&ms, e0, e1);
-		tot += ms;
-	}
-	return tot / reps;
-}
-extern "C" float tsqr_selftest_read_time(float* q, const float* a, size_t m, int mode, int waves, int reps) {
-	const int nch = (int)(m / 64);
-	const int cpw = (nch + waves - 1) / waves;
-	const int nwaves = (nch + cpw - 1) / cpw;
-	hipEvent_t e0, e1;
-	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-	for (int it = 0; it < reps + 1; it++) {
-		if (it == 1) (void)hipEventRecord(e0, 0);
-		if (mode == 0) hipLaunchKernelGGL(read_cq_kernel<0>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
-		else hipLaunchKernelGGL(read_cq_kernel<1>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
-	}
-	(void)hipEventRecord(e1, 0);
-	(void)hipEventSynchronize(e1);
-	float ms = 0.f;
-	(void)hipEventElapsedTime(&ms, e0, e1);
-	return ms / reps;
-}
-extern "C" float tsqr_selftest_copy_time(float* q, const float* a, size_t m, int mode, int waves, int reps) {
-	const int nch = (int)(m / 64);
-	const int cpw = (nch + waves - 1) / waves;
-	const int nwaves = (nch + cpw - 1) / cpw;
-	hipEvent_t e0, e1;
-	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-	for (int it = 0; it < reps + 1; it++) {
-		if (it == 1) (void)hipEventRecord(e0, 0);
-		if (mode == 0) hipLaunchKernelGGL(copy_cq_kernel<0>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
-		else hipLaunchKernelGGL(copy_cq_kernel<1>, dim3((nwaves + 3) / 4), dim3(256), 0, 0, q, a, m, m, nch, cpw, nwaves);
-	}
-	(void)hipEventRecord(e1, 0);
-	(void)hipEventSynchronize(e1);
-	float ms = 0.f;
-	(void)hipEventElapsedTime(&ms, e0, e1);
-	return ms / reps;
-}
-
-// ---- access-pattern study: copy A -> Q with an explicit leading dimension ----
-// PAT 0: wave = 64 rows x 64 cols, 64-B segments per column per instruction ((c,q) layout, what apply/gram use)
-// PAT 2: workgroup = 256 rows x 64 cols, every wave instruction moves 1 KB contiguous of ONE column (wave w: columns w, w+4, ...)
-// PAT 3: workgroup = 256 rows x 64 cols, wave w: columns 16w .. 16w+15 (one column tile), 1 KB per instruction
-template <int PAT, bool INTER>
-__global__ __launch_bounds__(256) void copy_pat_kernel(float* q, const float* a, size_t ld, size_t m, int nunits, int upw, int nworkers) {
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	if (PAT == 0) {
-		const int gw = blockIdx.x * 4 + wv;
-		if (gw >= nworkers) return;
-		const int c = lane & 15, qq = lane >> 4;
-		const int u_begin = INTER ? gw : gw * upw, u_end = INTER ? nunits : min(nunits, (gw + 1) * upw), u_step = INTER ? nworkers : 1;
-		for (int ch = u_begin; ch < u_end; ch += u_step) {
-			const size_t row0 = (size_t)ch * 64;
-			float p[4][16];
-			tsqrmi::load_chunk<4>(p, a, ld, row0, m, 64, c, qq);
-#pragma unroll
-			for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-				for (int rt = 0; rt < 4; rt++) {
-					tsqrmi::f32x4 v = {p[ct][4 * rt], p[ct][4 * rt + 1], p[ct][4 * rt + 2], p[ct][4 * rt + 3]};
-					*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)(16 * ct + c) * ld + row0 + 16 * rt + 4 * qq) = v;
-				}
-		}
-	} else {
-		const int wg = blockIdx.x;
-		const int u_begin = INTER ? wg : wg * upw, u_end = INTER ? nunits : min(nunits, (wg + 1) * upw), u_step = INTER ? nworkers : 1;
-		for (int b = u_begin; b < u_end; b += u_step) {
-			const size_t row0 = (size_t)b * 256;
-			tsqrmi::f32x4u v[16];
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				const int col = PAT == 2 ? wv + 4 * k : 16 * wv + k;
-				v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)col * ld + row0 + 4 * lane);
-			}
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				const int col = PAT == 2 ? wv + 4 * k : 16 * wv + k;
-				*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + 4 * lane) = v[k];
-			}
-		}
-	}
-}
-extern "C" float tsqr_selftest_copy_pat(float* q, const float* a, size_t ld, size_t m, int pat, int inter, int waves, int reps) {
-	hipEvent_t e0, e1;
-	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-	int nunits, workers;
-	if (pat == 0) { nunits = (int)(m / 64); workers = waves; } else { nunits = (int)(m / 256); workers = waves / 4; }
-	const int upw = (nunits + workers - 1) / workers;
-	const int nworkers = (nunits + upw - 1) / upw;
-	const int grid = pat == 0 ? (nworkers + 3) / 4 : nworkers;
-	for (int it = 0; it < reps + 1; it++) {
-		if (it == 1) (void)hipEventRecord(e0, 0);
-		if (pat == 0 && !inter) hipLaunchKernelGGL((copy_pat_kernel<0, false>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
-		else if (pat == 0) hipLaunchKernelGGL((copy_pat_kernel<0, true>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
-		else if (pat == 2 && !inter) hipLaunchKernelGGL((copy_pat_kernel<2, false>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
-		else if (pat == 2) hipLaunchKernelGGL((copy_pat_kernel<2, true>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
-		else if (pat == 3 && !inter) hipLaunchKernelGGL((copy_pat_kernel<3, false>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
-		else hipLaunchKernelGGL((copy_pat_kernel<3, true>), dim3(grid), dim3(256), 0, 0, q, a, ld, m, nunits, upw, nworkers);
-	}
-	(void)hipEventRecord(e1, 0);
-	(void)hipEventSynchronize(e1);
-	float ms = 0.f;
-	(void)hipEventElapsedTime(&ms, e0, e1);
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-	return ms / reps;
-}
-
-// ---- skeleton of a workgroup-cooperative streaming kernel: block = ROWS x 64 columns, global loads of ROWS*4 contiguous bytes
-// per column, transposition through LDS, next block prefetched into registers; output either as 64-B segments from the (c,q)
-// layout (OUT_LINEAR = false) or staged back through LDS and stored ROWS*4 contiguous bytes per column ----
-template <int ROWS, bool OUT_LINEAR>
-__global__ __launch_bounds__(256) void copy_wg_kernel(float* q, const float* a, size_t ld, size_t m, int nblocks, int nwg) {
-	constexpr int NP = 64, RS = ROWS + 4;
-	constexpr int LPC = ROWS / 4, CPI = 64 / LPC, NI = NP / (4 * CPI);
-	__shared__ __attribute__((aligned(16))) float As[NP * RS];
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int c = lane & 15, qq = lane >> 4;
-	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
-	tsqrmi::f32x4u v[NI];
-	int b = blockIdx.x;
-	if (b < nblocks) {
-#pragma unroll
-		for (int k = 0; k < NI; k++) v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)b * ROWS + lrow);
-	}
-	for (; b < nblocks; b += nwg) {
-#pragma unroll
-		for (int k = 0; k < NI; k++) *reinterpret_cast<tsqrmi::f32x4*>(&As[((wv + 4 * k) * CPI + lcol) * RS + lrow]) = v[k];
-		__syncthreads();
-		const int bn = b + nwg;
-		if (bn < nblocks) {
-#pragma unroll
-			for (int k = 0; k < NI; k++) v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)bn * ROWS + lrow);
-		}
-		const size_t row0 = (size_t)b * ROWS;
-		if (!OUT_LINEAR) {
-#pragma unroll
-			for (int s = 0; s < ROWS / 64; s++)
-#pragma unroll
-				for (int ct = 0; ct < 4; ct++) {
-					const int r = wv * (ROWS / 4) + 16 * s + 4 * qq;
-					const tsqrmi::f32x4 x = *reinterpret_cast<const tsqrmi::f32x4*>(&As[(16 * ct + c) * RS + r]);
-					*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)(16 * ct + c) * ld + row0 + r) = x;
-				}
-		} else {
-#pragma unroll
-			for (int k = 0; k < NI; k++) {
-				const int col = (wv + 4 * k) * CPI + lcol;
-				const tsqrmi::f32x4 x = *reinterpret_cast<const tsqrmi::f32x4*>(&As[col * RS + lrow]);
-#ifdef TSQR_SKELETON_CACHED_STORE
-				*reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + lrow) = x;
-#else
-				__builtin_nontemporal_store(x, reinterpret_cast<tsqrmi::f32x4u*>(q + (size_t)col * ld + row0 + lrow));
-#endif
-			}
-		}
-		__syncthreads();
-	}
-}
-extern "C" float tsqr_selftest_copy_wg(float* q, const float* a, size_t ld, size_t m, int rows, int out_linear, int nwg, int reps) {
-	hipEvent_t e0, e1;
-	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-	const int nblocks = (int)(m / rows);
-	if (nwg > nblocks) nwg = nblocks;
-	for (int it = 0; it < reps + 1; it++) {
-		if (it == 1) (void)hipEventRecord(e0, 0);
-		if (rows == 256 && out_linear) hipLaunchKernelGGL((copy_wg_kernel<256, true>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
-		else if (rows == 256) hipLaunchKernelGGL((copy_wg_kernel<256, false>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
-		else if (out_linear) hipLaunchKernelGGL((copy_wg_kernel<128, true>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
-		else hipLaunchKernelGGL((copy_wg_kernel<128, false>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
-	}
-	(void)hipEventRecord(e1, 0);
-	(void)hipEventSynchronize(e1);
-	float ms = 0.f;
-	(void)hipEventElapsedTime(&ms, e0, e1);
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-	return ms / reps;
 }
 
 // ---- launch-path costs: wall time per iteration of {k dependent tiny kernels [+ 4-byte D2H copy] + stream sync} ----
@@ -435,49 +132,6 @@ extern "C" double tsqr_selftest_launch_cost(unsigned* dev_word, unsigned* pinned
 	return std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
 }
 
-
-// ---- one-directional limits of the workgroup skeleton: MODE 0 copy (nontemporal stores), 1 load only, 2 store only (nontemporal) ----
-template <int MODE>
-__global__ __launch_bounds__(256) void stream_wg_kernel(float* q, const float* a, size_t ld, size_t m, int nblocks, int nwg) {
-	constexpr int ROWS = 128, NP = 64;
-	constexpr int LPC = ROWS / 4, CPI = 64 / LPC, NI = NP / (4 * CPI);
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
-	tsqrmi::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-	for (int b = blockIdx.x; b < nblocks; b += nwg) {
-		tsqrmi::f32x4 v[NI];
-#pragma unroll
-		for (int k = 0; k < NI; k++) {
-			const size_t off = (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)b * ROWS + lrow;
-			if (MODE != 2) v[k] = *reinterpret_cast<const tsqrmi::f32x4u*>(a + off);
-			else v[k] = tsqrmi::f32x4{(float)b, (float)k, 1.f, 2.f};
-		}
-#pragma unroll
-		for (int k = 0; k < NI; k++) {
-			const size_t off = (size_t)((wv + 4 * k) * CPI + lcol) * ld + (size_t)b * ROWS + lrow;
-			if (MODE != 1) __builtin_nontemporal_store(v[k], reinterpret_cast<tsqrmi::f32x4u*>(q + off));
-			else acc += v[k];
-		}
-	}
-	if (MODE == 1 && acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) q[0] = acc[0];
-}
-extern "C" float tsqr_selftest_stream_wg(float* q, const float* a, size_t ld, size_t m, int mode, int nwg, int reps) {
-	hipEvent_t e0, e1;
-	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-	const int nblocks = (int)(m / 128);
-	for (int it = 0; it < reps + 1; it++) {
-		if (it == 1) (void)hipEventRecord(e0, 0);
-		if (mode == 0) hipLaunchKernelGGL((stream_wg_kernel<0>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
-		else if (mode == 1) hipLaunchKernelGGL((stream_wg_kernel<1>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
-		else hipLaunchKernelGGL((stream_wg_kernel<2>), dim3(nwg), dim3(256), 0, 0, q, a, ld, m, nblocks, nwg);
-	}
-	(void)hipEventRecord(e1, 0);
-	(void)hipEventSynchronize(e1);
-	float ms = 0.f;
-	(void)hipEventElapsedTime(&ms, e0, e1);
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-	return ms / reps;
-}
 
 // ---- a sequence of skeleton passes over the same A / Q, each timed separately (what the two streaming passes of a call can reach
 // when they alternate): pass p = {mode: 0 copy (nt stores) / 1 load only / 2 store only / 3 load only in the per-wave (c,q) chunk pattern,

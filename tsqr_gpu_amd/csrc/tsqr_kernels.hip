@@ -200,16 +200,66 @@ __device__ __forceinline__ float fast_rcp(float a) {     // v_rcp_f32 + one Newt
 // column (r_kk - tau*w_k), so an inexact beta shows up as a tiny backward error, never as loss of orthogonality.
 //   glim : last 4-register group (16-row tile) of the chunk that carries data in this panel (3 for a dense chunk; the panel
 //          index when the chunk is an upper-triangular R block: rows below the panel's own row tile are zero)
-template <int KK, bool TRI>
+// Cooperative fold (fold_coop_kernel): the WAVES waves of a workgroup hold one 64-row block each of a stack [R; B_1; ...; B_{WAVES-1}]
+// and run ONE 64-step reflector chain for the whole stack.  What a reflector needs from all blocks is a sum over the waves: the
+// column inner products x_k^T x_c of a panel step (sixteen floats per wave) and V^T B of a block reflector (one accumulator tile
+// per wave and trailing tile).  Every wave adds the partial results of all waves in the same fixed order, so all of them hold
+// bit-identical reflectors and update their own copy of R in LDS identically -- no shared state besides the two exchange arrays.
+constexpr int FOLD_COOP_WAVES = 8;
+struct CoopCtx {
+	float* xd;                           // [2][WAVES][64]: column inner products of a step, double buffered by the step's parity
+	float* xw;                           // [3][WAVES][64][4]: V^T B accumulator tiles of a panel's trailing tiles
+	int wave;
+	int step;                            // running count of panel steps (parity selects the xd buffer)
+};
+template <bool COOP>
+__device__ __forceinline__ float coop_sum(float d, CoopCtx* cc) {
+	if constexpr (COOP) {
+		const int lane = threadIdx.x & 63;
+		float* buf = cc->xd + (cc->step & 1) * FOLD_COOP_WAVES * 64;
+		cc->step++;
+		buf[cc->wave * 64 + lane] = d;
+		lds_barrier();                                   // a buffer is rewritten two steps later: every wave has read it by then
+		float v[FOLD_COOP_WAVES];
+#pragma unroll
+		for (int w = 0; w < FOLD_COOP_WAVES; w++) v[w] = buf[w * 64 + lane];
+		float t = v[0];
+#pragma unroll
+		for (int w = 1; w < FOLD_COOP_WAVES; w++) t += v[w];    // (fixed order: bit-identical on every wave)
+		return t;
+	} else {
+		return d;
+	}
+}
+template <bool COOP>
+__device__ __forceinline__ f32x4 coop_sum4(f32x4 v, CoopCtx* cc, int slot) {
+	if constexpr (COOP) {
+		const int lane = threadIdx.x & 63;
+		f32x4* buf = reinterpret_cast<f32x4*>(cc->xw) + slot * FOLD_COOP_WAVES * 64;
+		buf[cc->wave * 64 + lane] = v;
+		lds_barrier();                                   // (a slot is rewritten one panel = at least sixteen step barriers later)
+		f32x4 u[FOLD_COOP_WAVES];
+#pragma unroll
+		for (int w = 0; w < FOLD_COOP_WAVES; w++) u[w] = buf[w * 64 + lane];
+		f32x4 t = u[0];
+#pragma unroll
+		for (int w = 1; w < FOLD_COOP_WAVES; w++) t += u[w];
+		return t;
+	} else {
+		return v;
+	}
+}
+
+template <int KK, bool TRI, bool COOP = false>
 __device__ __forceinline__ void panel_step(float (&p0)[16], float (&Trow)[16], float& sc, float* __restrict__ Rrow, int c,
-                                           float rkk, float rkc, int glim) {
+                                           float rkk, float rkc, int glim, CoopCtx* cc = nullptr) {
 	float acc = 0.0f;
 	static_for<0, 4>([&](auto g) {
 		constexpr int G = decltype(g)::value;
 		if (!TRI || G <= glim)                           // wave-uniform; compiled out for dense chunks
 			static_for<0, 4>([&](auto r) { fmac_bcast<KK, (TRI ? decltype(r)::value == 0 : 4 * G + decltype(r)::value == 0)>(acc, p0[4 * G + decltype(r)::value], p0[4 * G + decltype(r)::value]); });
 	});
-	const float d = xq_sum(acc);                         // x_k^T x_c for every column c of the tile
+	const float d = coop_sum<COOP>(xq_sum(acc), cc);     // x_k^T x_c for every column c of the tile (COOP: over the blocks of all waves)
 	const float ss = bcast16<KK>(d);                     // ||x_k||^2
 	const float nrm = __builtin_amdgcn_sqrtf(fmaf(rkk, rkk, ss));
 	const bool nz = nrm > 0.0f;
@@ -241,9 +291,10 @@ __device__ __forceinline__ void panel_step(float (&p0)[16], float (&Trow)[16], f
 // block reflector of the finished panel applied to one trailing tile (all operands in registers / LDS rows of R)
 //   pj: trailing tile;  v: V of the panel in (c,q) layout (scaled);  vt[rt]: -V^T pieces (lane <-> row in tile rt)
 //   ta[r] = T[4q+r][c];  Rp: packed R in LDS;  K0: first column of the panel;  colj: first column of the trailing tile
-template <bool TRI>
+template <bool TRI, bool COOP = false>
 __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[16], const f32x4 (&vt)[4], const float (&ta)[4],
-                                             float* __restrict__ Rp, int K0, int colj, int NP, int c, int q, int glim) {
+                                             float* __restrict__ Rp, int K0, int colj, int NP, int c, int q, int glim,
+                                             CoopCtx* cc = nullptr, int slot = 0) {
 	// W0 = rows K0..K0+15 of R restricted to this tile, D layout (row 4q+r, column c)
 	int idx[4];
 	f32x4 w0;
@@ -254,12 +305,14 @@ __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[1
 		w0[r] = Rp[idx[r]];
 	}
 	f32x4 w = w0;                                        // W = W0 + V^T B
+	if constexpr (COOP) { if (cc->wave != 0) w = f32x4{0.f, 0.f, 0.f, 0.f}; }   // (the rows of R enter the sum once)
 #pragma unroll
 	for (int rt = 0; rt < 4; rt++)
 		if (!TRI || rt <= glim) {                        // V is zero in the row tiles below the panel of a triangular block
 #pragma unroll
 			for (int r = 0; r < 4; r++) w = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * rt + r], pj[4 * rt + r], w, 0, 0, 0);
 		}
+	w = coop_sum4<COOP>(w, cc, slot);
 	f32x4 wp = {0.f, 0.f, 0.f, 0.f};                     // W' = T^T W   (k-slot (q, r) <-> panel column 4q+r)
 #pragma unroll
 	for (int r = 0; r < 4; r++) wp = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[r], w[r], wp, 0, 0, 0);
@@ -285,10 +338,11 @@ __device__ __forceinline__ void trail_update(float (&pj)[16], const float (&v)[1
 //                    (vt, from the exact fp32-MFMA transposition) in k-slots 0..3 and zeros in 4..7, W' supplies the same slots;
 //   W' = T^T W     : 16 x 16 x 16, stays on the exact fp32 MFMA.
 // vh/vm/vl[kt]: split of V per K-step; th/tm/tl[rt]: split of the padded -V^T slices (both prepared once per panel).
-template <bool TRI>
+template <bool TRI, bool COOP = false>
 __device__ __forceinline__ void trail_update_cor(float (&pj)[16], const bf16x8 (&vh)[2], const bf16x8 (&vm)[2], const bf16x8 (&vl)[2],
                                                  const bf16x8 (&th)[4], const bf16x8 (&tm)[4], const bf16x8 (&tl)[4], const float (&ta)[4],
-                                                 float* __restrict__ Rp, int K0, int colj, int NP, int c, int q, int glim) {
+                                                 float* __restrict__ Rp, int K0, int colj, int NP, int c, int q, int glim,
+                                                 CoopCtx* cc = nullptr, int slot = 0) {
 	int idx[4];
 	f32x4 w0;
 #pragma unroll
@@ -298,6 +352,7 @@ __device__ __forceinline__ void trail_update_cor(float (&pj)[16], const bf16x8 (
 		w0[r] = Rp[idx[r]];
 	}
 	f32x4 w = w0;                                        // W = W0 + V^T B
+	if constexpr (COOP) { if (cc->wave != 0) w = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
 	for (int kt = 0; kt < 2; kt++)
 		if (!TRI || 2 * kt <= glim) {                    // rows 32 kt .. are zero in a triangular block beyond row tile glim
@@ -316,6 +371,7 @@ __device__ __forceinline__ void trail_update_cor(float (&pj)[16], const bf16x8 (
 			w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vm[kt], bh, w, 0, 0, 0);
 			w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[kt], bh, w, 0, 0, 0);
 		}
+	w = coop_sum4<COOP>(w, cc, slot);
 	f32x4 wp = {0.f, 0.f, 0.f, 0.f};                     // W' = T^T W   (k-slot (q, r) <-> panel column 4q+r), exact fp32
 #pragma unroll
 	for (int r = 0; r < 4; r++) wp = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[r], w[r], wp, 0, 0, 0);
@@ -345,8 +401,9 @@ __device__ __forceinline__ void trail_update_cor(float (&pj)[16], const bf16x8 (
 // R <- R-factor of [R ; chunk].  TRI: the chunk is itself a 64-row upper-triangular block (panel S is zero below row tile S).
 // COR: fp32_tc_cor -- the block reflector is applied with the bf16x3 error-corrected MFMA products (trail_update_cor), otherwise
 // with exact fp32 MFMA (fp32_notc).  p is consumed (the register tiles rotate).
-template <int NT, bool TRI, bool COR>
-__device__ __forceinline__ void fold_one(float (&p)[NT][16], float* __restrict__ Rw, float* __restrict__ Tl, int n, int c, int q) {
+template <int NT, bool TRI, bool COR, bool COOP = false>
+__device__ __forceinline__ void fold_one(float (&p)[NT][16], float* __restrict__ Rw, float* __restrict__ Tl, int n, int c, int q,
+                                         CoopCtx* cc = nullptr) {
 	constexpr int NP = 16 * NT;
 	const int ntile = (n + 15) >> 4;                     // tiles that carry data
 #pragma unroll 1
@@ -364,7 +421,7 @@ __device__ __forceinline__ void fold_one(float (&p)[NT][16], float* __restrict__
 			const int offN = offK + NP - (K0 + KK);      // row K+1
 			float rkk_n = 0.0f, rkc_n = 0.0f;
 			if (KK < 15) { rkk_n = Rw[offN]; rkc_n = Rw[offN + c - (KK + 1)]; }   // not touched by step KK
-			if (K0 + KK < n) panel_step<KK, TRI>(p[0], Trow, sc, Rw + offK, c, rkk, rkc, glim);
+			if (K0 + KK < n) panel_step<KK, TRI, COOP>(p[0], Trow, sc, Rw + offK, c, rkk, rkc, glim, cc);
 			offK = offN; rkk = rkk_n; rkc = rkc_n;
 		});
 		const int ntrail = ntile - 1 - S;
@@ -417,12 +474,12 @@ __device__ __forceinline__ void fold_one(float (&p)[NT][16], float* __restrict__
 				}
 				static_for<1, NT>([&](auto jj) {
 					constexpr int J = decltype(jj)::value;
-					if (J <= ntrail) trail_update_cor<TRI>(p[J], vh, vm, vl, th, tm, tl, ta, Rw, K0, K0 + 16 * J, NP, c, q, glim);
+					if (J <= ntrail) trail_update_cor<TRI, COOP>(p[J], vh, vm, vl, th, tm, tl, ta, Rw, K0, K0 + 16 * J, NP, c, q, glim, cc, J - 1);
 				});
 			} else {
 				static_for<1, NT>([&](auto jj) {
 					constexpr int J = decltype(jj)::value;
-					if (J <= ntrail) trail_update<TRI>(p[J], p[0], vt, ta, Rw, K0, K0 + 16 * J, NP, c, q, glim);
+					if (J <= ntrail) trail_update<TRI, COOP>(p[J], p[0], vt, ta, Rw, K0, K0 + 16 * J, NP, c, q, glim, cc, J - 1);
 				});
 			}
 			__builtin_amdgcn_wave_barrier();
@@ -497,70 +554,61 @@ __global__ __launch_bounds__(256, 2) void fold_kernel(const FoldArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// fold_tree_kernel: the binary R-stack reduction of the reference (src/tsqr.cu:1121-1172: one launch per level) collapsed:
-// a workgroup of 8 waves (two per SIMD: the fold needs ~200 VGPRs) reduces up to 8 * per_wave triangular 64 x 64 blocks of the stack
-// to ONE -- every wave first folds its own per_wave consecutive blocks (the first is copied), then three levels of pairwise folds run
-// inside the workgroup, the partner's packed R travelling through LDS.  2048 level-0 factors become R in three launches (128
-// workgroups, 8, 1) instead of eleven; every fold is still the latency-bound 64-step chain (11 of them on the critical path).
-// NT == 4 (49 <= n <= 64) only; narrower panels keep the per-level launches.
+// fold_coop_kernel (round 3): the binary R-stack reduction of the reference (src/tsqr.cu:1121-1172: one launch per level, 2 n x n
+// tiles each) as COOPERATIVE folds.  A binary tree over 2048 level-0 factors is eleven dependent 64-step reflector chains of ~27 us
+// each whoever launches them (round 2's fold_tree_kernel: 320-350 us); here a workgroup of eight waves folds EIGHT stacked
+// triangular 64 x 64 blocks in ONE chain -- block 0 is the running R (every wave keeps an identical copy in LDS), block w is wave
+// w's chunk, and what a reflector needs from all blocks travels through LDS once per step (CoopCtx) -- so 2048 factors need four
+// chains (2048 -> 256 -> 32 -> 4 -> 1, ~50 us each: 195-205 us).  NT == 4 (49 <= n <= 64) only; narrower panels keep the
+// per-level launches of fold_kernel.
 // ---------------------------------------------------------------------------------------------
 struct FoldTreeArgs {
 	const float* src; size_t ld;        // stack of nblocks upper-triangular 64 x 64 blocks: block b = rows 64 b .. 64 b + 63, column-major, leading dimension ld
-	int nblocks, per_wave, n;
+	int nblocks, n;
 	float* dst; size_t dst_ld;          // workgroup g writes its R at rows g * rows_store of dst
 	int rows_store, cols_store;
 };
-constexpr int FOLD_TREE_WAVES = 8;
+constexpr int FOLD_COOP_LDS_FLOATS = FOLD_COOP_WAVES * ((64 * 65) / 2 + 16) + FOLD_COOP_WAVES * 256 + 2 * FOLD_COOP_WAVES * 64 + 3 * FOLD_COOP_WAVES * 256;
 template <bool COR>
-__global__ __launch_bounds__(64 * FOLD_TREE_WAVES) void fold_tree_kernel(const FoldTreeArgs a) {
-	constexpr int NT = 4, NP = 64, WAVES = FOLD_TREE_WAVES;
+__global__ __launch_bounds__(64 * FOLD_COOP_WAVES) void fold_coop_kernel(const FoldTreeArgs a) {
+	constexpr int NT = 4, NP = 64, WAVES = FOLD_COOP_WAVES;
 	constexpr int RP = (NP * (NP + 1)) / 2 + 16;
-	extern __shared__ __attribute__((aligned(16))) char tree_smem[];     // Rs[WAVES][RP] + Ts[WAVES][256] floats
-	float* Rs = reinterpret_cast<float*>(tree_smem);
+	extern __shared__ __attribute__((aligned(16))) char coop_smem[];     // Rs[WAVES][RP] | Ts[WAVES][256] | xd[2][WAVES][64] | xw[3][WAVES][256]
+	float* Rs = reinterpret_cast<float*>(coop_smem);
 	float* Ts = Rs + WAVES * RP;
+	CoopCtx cc;
+	cc.xd = Ts + WAVES * 256;
+	cc.xw = cc.xd + 2 * WAVES * 64;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	cc.wave = wv; cc.step = 0;
 	const int c = lane & 15, q = lane >> 4;
 	float* Rw = Rs + wv * RP;
 	float* Tl = Ts + wv * 256;
 	for (int i = lane; i < RP; i += 64) Rw[i] = 0.0f;
-	const int first = (blockIdx.x * WAVES + wv) * a.per_wave;
-	const int last = min(a.nblocks, first + a.per_wave);
+	const int first = blockIdx.x * WAVES;                // this workgroup's blocks: first .. first + WAVES - 1 (those that exist)
 	const size_t mrows = (size_t)a.nblocks * 64;
 	float p[NT][16];
-	if (first < last) {
-		load_chunk<NT>(p, a.src, a.ld, (size_t)first * 64, mrows, a.n, c, q);
+	// block `first` is the initial R of every wave: loaded like any chunk and scattered into the packed rows
+	load_chunk<NT>(p, a.src, a.ld, (size_t)first * 64, mrows, a.n, c, q);
+#pragma unroll
+	for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+		for (int rho = 0; rho < 16; rho++) {
+			const int row = 16 * (rho >> 2) + 4 * q + (rho & 3), col = 16 * ct + c;
+			if (col >= row) Rw[row * NP - (row * (row - 1)) / 2 + col - row] = p[ct][rho];
+		}
+	// wave w > 0 folds block first + w; wave 0 (and a wave whose block does not exist) contributes a zero chunk
+	if (wv > 0 && first + wv < a.nblocks) {
+		load_chunk<NT>(p, a.src, a.ld, (size_t)(first + wv) * 64, mrows, a.n, c, q);
+	} else {
 #pragma unroll
 		for (int ct = 0; ct < NT; ct++)
 #pragma unroll
-			for (int rho = 0; rho < 16; rho++) {
-				const int row = 16 * (rho >> 2) + 4 * q + (rho & 3), col = 16 * ct + c;
-				if (col >= row) Rw[row * NP - (row * (row - 1)) / 2 + col - row] = p[ct][rho];
-			}
-		__builtin_amdgcn_wave_barrier();
-		for (int b = first + 1; b < last; b++) {
-			load_chunk<NT>(p, a.src, a.ld, (size_t)b * 64, mrows, a.n, c, q);
-			fold_one<NT, true, COR>(p, Rw, Tl, a.n, c, q);
-		}
+			for (int rho = 0; rho < 16; rho++) p[ct][rho] = 0.0f;
 	}
-	// waves of this workgroup that hold a factor: those whose first block exists
-	const int wg_first = blockIdx.x * WAVES * a.per_wave;
-	const int active = min(WAVES, (max(a.nblocks - wg_first, 0) + a.per_wave - 1) / a.per_wave);
-#pragma unroll 1
-	for (int s = 1; s < WAVES; s *= 2) {
-		__syncthreads();                                 // the partners' factors of this level are complete
-		if ((wv & (2 * s - 1)) == 0 && wv + s < active) {
-			const float* Rp = Rs + (wv + s) * RP;            // partner's packed upper triangle -> chunk registers
-#pragma unroll
-			for (int ct = 0; ct < NT; ct++)
-#pragma unroll
-				for (int rho = 0; rho < 16; rho++) {
-					const int row = 16 * (rho >> 2) + 4 * q + (rho & 3), col = 16 * ct + c;
-					p[ct][rho] = (col >= row) ? Rp[row * NP - (row * (row - 1)) / 2 + col - row] : 0.0f;
-				}
-			fold_one<NT, true, COR>(p, Rw, Tl, a.n, c, q);
-		}
-	}
+	__builtin_amdgcn_wave_barrier();
+	fold_one<NT, true, COR, true>(p, Rw, Tl, a.n, c, q, &cc);
 	if (wv == 0) store_packed_r<NP>(a.dst + (size_t)blockIdx.x * a.rows_store, a.dst_ld, Rw, a.rows_store, a.cols_store, lane);
 }
 
@@ -588,16 +636,12 @@ struct GramArgs {
 	double* part;                        // [gridDim.x][NTRI][256]  (tile, lane, reg) order of the MFMA accumulators
 	const unsigned* skip_status;         // optional: return at once when *skip_status != 0 (an earlier, speculatively enqueued
 	                                     // sweep this pass depends on was rejected; its successor Cholesky reports "rejected" too)
-	unsigned* ticket_zero;               // optional: arrival counter of the gram_reduce_chol_kernel launch that follows; zeroed here (the
-	                                     // work buffer is the caller's, uninitialised memory: every counted launch has a Gram launch,
-	                                     // or a counted launch that reset the counter, in front of it on the stream)
 };
 
 template <int NT>
 __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
-	if (a.ticket_zero && blockIdx.x == 0 && threadIdx.x == 0) *a.ticket_zero = 0u;
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
@@ -671,7 +715,6 @@ template <int NT>
 __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
-	if (a.ticket_zero && blockIdx.x == 0 && threadIdx.x == 0) *a.ticket_zero = 0u;
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
@@ -819,6 +862,17 @@ __device__ __forceinline__ double bcast_lane_f64(double x, int lane_const) {
 	return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// In-kernel time stamps of the Cholesky step (diagnostic builds only: the selftest library is compiled with -DTSQR_CHOL_STAMPS, the
+// product library never is).  Lane 0 of every wave notes the shader clock (s_memtime) in LDS; the kernel dumps the table at its end.
+#ifdef TSQR_CHOL_STAMPS
+__device__ unsigned long long* g_chol_stamp_out = nullptr;           // [4 waves][CHOL_NSTAMP] + [4] s_memrealtime pairs
+constexpr int CHOL_NSTAMP = 160;
+__shared__ unsigned long long chol_stamp_lds[4 * CHOL_NSTAMP];
+#define CHOL_STAMP(slot) do { if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHOL_STAMP(slot) do {} while (0)
+#endif
+
 // Row ownership of the elimination kernels: thread (w, j) holds column j of the rows  row(w, s) = 16*(s>>2) + 4*w + (s&3),
 // i.e. every wave owns FOUR consecutive rows of each 16-row block.  A "group" = those four rows: its owner factors them
 // against each other in registers (lane broadcasts, no LDS), publishes the four finished rows, and after ONE barrier all
@@ -831,6 +885,7 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
 	double* rr = Rrow + (U & 1) * 256;                   // [4][64]
 	double* mr = Mrow + (U & 1) * 256;
+	CHOL_STAMP(8 + 8 * (4 * kk + U) + 0);
 	if (w == U) {
 		// the owner's section is the critical path (three waves wait at the barrier): nothing but the pivots, the two row
 		// scalings, the in-group eliminations and the publication of the rows; fp32 copies, Z and the verdict sums are taken
@@ -856,7 +911,9 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 			if (j == 0 && live) pv[K] = piv0;
 		});
 	}
+	CHOL_STAMP(8 + 8 * (4 * kk + U) + 1);
 	__syncthreads();
+	CHOL_STAMP(8 + 8 * (4 * kk + U) + 2);
 	double rkj[4], mkc[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++) { rkj[u] = rr[u * 64 + j]; mkc[u] = mr[u * 64 + j]; }
@@ -887,168 +944,12 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 			g[s] = acc_g; mm[s] = acc_m;
 		}
 	}
-}
-
-// In-kernel time stamps of the Cholesky step (diagnostic builds only: the selftest library is compiled with -DTSQR_CHOL_STAMPS, the
-// product library never is).  Lane 0 of every wave notes the shader clock (s_memtime) in LDS; the kernel dumps the table at its end.
-#ifdef TSQR_CHOL_STAMPS
-__device__ unsigned long long* g_chol_stamp_out = nullptr;           // [4 waves][CHOL_NSTAMP] + [4] s_memrealtime pairs
-constexpr int CHOL_NSTAMP = 160;
-__shared__ unsigned long long chol_stamp_lds[4 * CHOL_NSTAMP];
-#define CHOL_STAMP(slot) do { if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define CHOL_STAMP(slot) do {} while (0)
-#endif
-
-// rank-4 update of the register rows LO .. HI-1 (whole groups of four: LO, HI multiples of 4) of one wave with the four published rows
-// of a group (rr: [4][64] in LDS).  KK (the 16-row block, compile time) fixes which register rows still exist, so the code is free of
-// branches: all LDS reads of a call are independent of its arithmetic and can be issued back to back (a join between two loads makes
-// the compiler wait for the first: the round-2 form took 18-30 cycles per FMA here, tools/chol_stamps.py).  The four rows of a
-// register group are consecutive rows of the matrix: R[K0+u][i .. i+3] are two 16-byte LDS broadcasts.
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-template <int LO, int HI, int KK, bool WITH_M>
-__device__ __forceinline__ void chol_update_slots(double (&g)[16], double (&mm)[16], const double* rr, const double (&rkj)[4], const double (&mkc)[4], int w) {
-	constexpr int NLIVE = 16 - 4 * KK;
-	constexpr int H = HI < NLIVE ? HI : NLIVE;
-	static_assert(LO % 4 == 0 && HI % 4 == 0, "whole register groups");
-	if constexpr (LO < H) {
-		f64x2 ra[(H - LO) / 4][4][2];
-#pragma unroll
-		for (int sg = LO / 4; sg < H / 4; sg++)
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const double* p = rr + u * 64 + 16 * (KK + sg) + 4 * w;
-				ra[sg - LO / 4][u][0] = *reinterpret_cast<const f64x2*>(p);
-				ra[sg - LO / 4][u][1] = *reinterpret_cast<const f64x2*>(p + 2);
-			}
-#pragma unroll
-		for (int s = LO; s < H; s++) {
-			double acc_g = g[s], acc_m = mm[s];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const double rki = ra[(s - LO) >> 2][u][(s & 3) >> 1][s & 1];     // R[K0+u][i]
-				acc_g = fma(-rki, rkj[u], acc_g);
-				if constexpr (WITH_M) acc_m = fma(-rki, mkc[u], acc_m);
-			}
-			g[s] = acc_g;
-			if constexpr (WITH_M) mm[s] = acc_m;
-		}
-	}
-}
-
-__device__ __forceinline__ double rsq_newton(double p) {     // v_rsq_f64 (~2^-23) + one Newton step (~2^-45)
-	const double y = __builtin_amdgcn_rsq(p);
-	return fma(0.5 * y, fma(-p * y, y, 1.0), y);
-}
-
-// chol_group2: the same elimination step with a shorter critical path (round 3).  Three changes against chol_group:
-//  * the owner first makes the 4 x 4 diagonal block of its group wave-uniform (ten lane reads, issued back to back) and factors it in
-//    uniform arithmetic: the chain pivot -> rsqrt -> Newton -> row scaling -> next pivot no longer passes through a lane read (VALU ->
-//    SGPR -> VALU) twice per pivot and pair; the four rows of R and of M are then formed for all 64 columns by the 4 x 4 forward
-//    substitution with those uniform multipliers -- independent work that fills the latency gaps of the chain;
-//  * look-ahead: after the barrier the NEXT owner updates only the four rows of its own group, factors and publishes them; the rest
-//    of that update (its rows 4..) is applied after ITS barrier, together with the update of its own group -- off the path, like
-//    every other wave's updates and the verdict bookkeeping (a full 16-row update is ~130 fp64 FMAs = ~1000 cycles of issue: in
-//    chol_group the next owner paid them before it could start);
-//  * the published rows therefore live in THREE rotating LDS buffers: a group's rows are still read (by the previous owner's
-//    deferred update) while the next owner publishes.
-// The arithmetic per entry is the same sequence of fma / multiplications as in chol_group (same results).
-// Rrow / Mrow: [3][4][64] doubles.  deferred: this wave still owes its rows 4.. the update of the group before the current one.
-template <int KK, int U>
-__device__ __forceinline__ void chol_group2(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* Zf, double* Zd,
-                                            double* pv, int w, int j, int n, double dgj, double& s_acc, bool& deferred) {
-	constexpr int K0 = 16 * KK + 4 * U;
-	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
-	constexpr int gi = 4 * KK + U;                       // group index 0..15
-	constexpr int bcur = gi % 3, bprev = (gi + 2) % 3;
-	double* rr = Rrow + bcur * 256;                      // [4][64]
-	double* mr = Mrow + bcur * 256;
-	CHOL_STAMP(8 + 8 * gi + 0);
-	if (w == U) {
-		// the 4 x 4 diagonal block, wave-uniform (row u of the group is register u; column K0+v is lane K0+v)
-		const double a00 = bcast_lane_f64(g[0], K0), a01 = bcast_lane_f64(g[0], K0 + 1), a02 = bcast_lane_f64(g[0], K0 + 2), a03 = bcast_lane_f64(g[0], K0 + 3);
-		const double a11 = bcast_lane_f64(g[1], K0 + 1), a12 = bcast_lane_f64(g[1], K0 + 2), a13 = bcast_lane_f64(g[1], K0 + 3);
-		const double a22 = bcast_lane_f64(g[2], K0 + 2), a23 = bcast_lane_f64(g[2], K0 + 3);
-		const double a33 = bcast_lane_f64(g[3], K0 + 3);
-		CHOL_STAMP(8 + 8 * gi + 1);
-		const double p0 = (a00 > 0.0) ? a00 : 1.0;       // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
-		const double y0 = rsq_newton(p0);
-		const double l01 = a01 * y0, l02 = a02 * y0, l03 = a03 * y0;
-		const double d1 = fma(-l01, l01, a11);
-		const double p1 = (d1 > 0.0) ? d1 : 1.0;
-		const double y1 = rsq_newton(p1);
-		const double l12 = fma(-l01, l02, a12) * y1, l13 = fma(-l01, l03, a13) * y1;
-		const double d2 = fma(-l12, l12, fma(-l02, l02, a22));
-		const double p2 = (d2 > 0.0) ? d2 : 1.0;
-		const double y2 = rsq_newton(p2);
-		const double l23 = fma(-l12, l13, fma(-l02, l03, a23)) * y2;
-		const double d3 = fma(-l23, l23, fma(-l13, l13, fma(-l03, l03, a33)));
-		const double p3 = (d3 > 0.0) ? d3 : 1.0;
-		const double y3 = rsq_newton(p3);
-		// rows of R and M for every column: forward substitution with the uniform multipliers
-		const double r0 = g[0] * y0, m0 = mm[0] * y0;
-		const double r1 = fma(-l01, r0, g[1]) * y1, m1 = fma(-l01, m0, mm[1]) * y1;
-		const double r2 = fma(-l12, r1, fma(-l02, r0, g[2])) * y2, m2 = fma(-l12, m1, fma(-l02, m0, mm[2])) * y2;
-		const double r3 = fma(-l23, r2, fma(-l13, r1, fma(-l03, r0, g[3]))) * y3, m3 = fma(-l23, m2, fma(-l13, m1, fma(-l03, m0, mm[3]))) * y3;
-		const double rv[4] = {r0, r1, r2, r3}, mv[4] = {m0, m1, m2, m3}, pvv[4] = {p0, p1, p2, p3}, yv[4] = {y0, y1, y2, y3}, dv[4] = {a00, d1, d2, d3};
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			const int K = K0 + u;
-			const bool live = K < n;
-			rr[u * 64 + j] = !live ? 0.0 : ((j > K) ? rv[u] : ((j == K) ? pvv[u] * yv[u] : 0.0));
-			mr[u * 64 + j] = live ? mv[u] : 0.0;
-			if (j == 0 && live) pv[K] = dv[u];
-		}
-		CHOL_STAMP(8 + 8 * gi + 2);
-	}
-	CHOL_STAMP(8 + 8 * gi + 3);
-	__syncthreads();
-	CHOL_STAMP(8 + 8 * gi + 4);
-	double rkj[4], mkc[4];
-#pragma unroll
-	for (int u = 0; u < 4; u++) { rkj[u] = rr[u * 64 + j]; mkc[u] = mr[u * 64 + j]; }
-	const bool next_exists = K0 + 4 < n;
-	if (next_exists && w == ((U + 1) & 3)) {
-		// next owner: only the four rows of its own group now (slots 0..3; after the last group of a 16-row block they are slots 4..7,
-		// which the rotation at the end of the block moves to 0..3); its rows 4.. (in the numbering after that rotation) follow
-		// after the next barrier
-		if constexpr (U < 3) chol_update_slots<0, 4, KK, true>(g, mm, rr, rkj, mkc, w);
-		else chol_update_slots<4, 8, KK, true>(g, mm, rr, rkj, mkc, w);
-		deferred = true;
-		CHOL_STAMP(8 + 8 * gi + 5);
-		return;
-	}
-	if (w == U && deferred) {
-		// this group's owner: first the update it still owes from the group before (those rows sit in the third buffer: the next
-		// owner publishes into the one after)
-		const double* rp = Rrow + bprev * 256;
-		const double* mp = Mrow + bprev * 256;
-		double rkp[4], mkp[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) { rkp[u] = rp[u * 64 + j]; mkp[u] = mp[u * 64 + j]; }
-		chol_update_slots<4, 16, KK, true>(g, mm, rp, rkp, mkp, w);
-		deferred = false;
-	}
-	if (w == ((U + 3) & 3)) {                            // the previous owner: neither the owner nor the next one
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			const int K = K0 + u;
-			if (K < n) {
-				Rf[K * 65 + j] = (float)rkj[u];
-				Zf[K * 65 + j] = (j <= K) ? (float)mkc[u] : 0.0f;                    // Z[j][K] = M[K][j]
-				Zd[K * 65 + j] = (j <= K) ? mkc[u] : 0.0;                            // (fp64 image, read on by chol_wide_kernel)
-				if (j <= K) s_acc = fma(dgj * mkc[u], mkc[u], s_acc);                // sum of g_jj * Z[j][K]^2
-			}
-		}
-	}
-	if (w <= U) chol_update_slots<4, 16, KK, true>(g, mm, rr, rkj, mkc, w);   // (slots 0..3 of waves <= U are finished rows)
-	else chol_update_slots<0, 16, KK, true>(g, mm, rr, rkj, mkc, w);
-	CHOL_STAMP(8 + 8 * gi + 5);
+	CHOL_STAMP(8 + 8 * (4 * kk + U) + 3);
 }
 
 // LOADG: functor e -> G tile entry e (accumulator order); host_status: optional device-visible alias of pinned host memory
 // that receives the three status words as well (the host then needs no copy operation to read them).
-template <bool V2 = false, class LOADG>
+template <class LOADG>
 __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
                                           float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double** gs_out = nullptr) {
@@ -1057,7 +958,7 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	__shared__ float Rf[64 * 65];                // R rows for the final store
 	__shared__ float Zf[64 * 65];                // rows of M = columns of Z for the final store (no global store inside the loop:
 	                                             // a workgroup barrier drains vmcnt, i.e. would wait for the store's round trip)
-	__shared__ double Rrow[3 * 256], Mrow[3 * 256], dg[64], pv[64];   // published rows: two (chol_group) / three (chol_group2) rotating buffers
+	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
 	const int t = threadIdx.x;
 	const int j = t & 63, w = t >> 6;
 	const int NP = 16 * NT;
@@ -1122,24 +1023,12 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	const double dgj = Gs[j * 65 + j];
 	double s_acc = 0.0;
 	__syncthreads();
-	bool deferred = false;                               // (V2) this wave still owes its rows 4.. the previous group's update
 	CHOL_STAMP(1);
-	if constexpr (V2) {
-		// the 16 groups as straight-line code: the block index is a compile-time constant in every group (which register rows are
-		// alive, the LDS buffer of the group, the lanes of its diagonal block), and the rotation of the rows is a renaming
-		static_for<0, 4>([&](auto kc) {
-			constexpr int KK = decltype(kc)::value;
-			static_for<0, 4>([&](auto u) { chol_group2<KK, decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, Gs, pv, w, j, n, dgj, s_acc, deferred); });
-#pragma unroll
-			for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }
-		});
-	} else {
 #pragma unroll 1
-		for (int kk = 0; kk < 4; kk++) {
-			static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, Gs, pv, w, j, n, kk, dgj, s_acc); });
+	for (int kk = 0; kk < 4; kk++) {
+		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, Gs, pv, w, j, n, kk, dgj, s_acc); });
 #pragma unroll
-			for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
-		}
+		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
 	}
 	// scaled conditioning S = || D * inverse(R) ||_F^2 / n with D = diag(sqrt(g_jj)): 1 for orthogonal columns of any scaling,
 	// ~cond^2 of the column-scaled matrix otherwise.  An entry-wise error eps*sqrt(g_ii g_jj) of G perturbs Q^T Q by <= eps*n*S.
@@ -1203,325 +1092,6 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// chol_body3 (round 3): the same step -- R = chol(G), Z = inverse(R), verdict -- reorganised after in-kernel time stamps of chol_body
-// (tools/chol_stamps.py; profiles/r03_experiment_log.md): a group of four pivots cost ~2000-4700 cycles there, of which the pivot
-// chain is ~500; the rest was fp64 issue (a wave issues one v_fma_f64 per ~8-12 cycles, and every wave carried the rows of
-// M = R^-T through the elimination as well: 130 FMAs + 64 LDS reads per group and wave) in front of the next owner's chain.
-//   phase 1  elimination of G alone, groups of four pivots owned by the waves in turn:
-//            * the owner makes the 4 x 4 diagonal block of its group wave-uniform (ten lane reads issued back to back), factors it in
-//              uniform arithmetic and forms its four rows of R for all columns by the 4 x 4 forward substitution with those
-//              multipliers (independent work in the latency gaps of the pivot chain: rsqrt -> Newton -> scale -> next pivot);
-//            * look-ahead: after the barrier the NEXT owner updates only the four rows of its own group and starts; everything else
-//              (the other waves' updates, the owner's own remaining rows, the copy of the finished rows into the LDS image of R)
-//              is off the path.  The published rows rotate through three LDS buffers for that.
-//   phase 2  Z = inverse(R) by 16 x 16 blocks from the finished fp64 R: the four diagonal blocks by back substitution (one wave
-//            each), then the block diagonals above it, Z_ab = -Z_aa (sum_k R_ak Z_kb), the terms of a sum spread over the waves.
-//            ~n^3/6 FMAs in all instead of the ~n^3/2 that carrying M through the elimination costs in SIMD form.
-//   phase 3  verdict (pivot ratios, scaled conditioning S) and the fp32 images of R and Z, coalesced.
-// R and Z live in LDS column-major with leading dimension 65 (Rc[k * 65 + i] = R[i][k], Zc[k * 65 + i] = Z[i][k]; Zc is also what
-// chol_wide_kernel reads on).  Same interface and same status words as chol_body.
-// ---------------------------------------------------------------------------------------------
-template <int LO, int HI>
-__device__ __forceinline__ void chol3_update(double (&g)[16], const double* rr, const double (&rkj)[4], int w, int kk, int nlive) {
-#pragma unroll
-	for (int s = LO; s < HI; s++) {
-		if (s < nlive) {                                     // wave-uniform
-			const int i = 16 * (kk + (s >> 2)) + 4 * w + (s & 3);
-			double acc = g[s];
-#pragma unroll
-			for (int u = 0; u < 4; u++) acc = fma(-rr[u * 64 + i], rkj[u], acc);   // R[K0+u][i]: one word for every lane (LDS broadcast)
-			g[s] = acc;
-		}
-	}
-}
-
-template <int U>
-__device__ __forceinline__ void chol3_group(double (&g)[16], double* Rrow, double* Rc, double* pv, double* yinv,
-                                            int w, int j, int n, int kk, bool& deferred) {
-	const int K0 = 16 * kk + 4 * U;
-	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
-	const int gi = 4 * kk + U;                           // group index 0..15
-	double* rr = Rrow + (gi % 3) * 256;                  // this group's four rows: [4][64]
-	const int nlive = 16 - 4 * kk;                       // register rows that still exist
-	CHOL_STAMP(8 + 8 * gi + 0);
-	if (w == U) {
-		// the 4 x 4 diagonal block, wave-uniform (row u of the group is register u; column K0+v is lane K0+v)
-		const double a00 = bcast_lane_f64(g[0], K0), a01 = bcast_lane_f64(g[0], K0 + 1), a02 = bcast_lane_f64(g[0], K0 + 2), a03 = bcast_lane_f64(g[0], K0 + 3);
-		const double a11 = bcast_lane_f64(g[1], K0 + 1), a12 = bcast_lane_f64(g[1], K0 + 2), a13 = bcast_lane_f64(g[1], K0 + 3);
-		const double a22 = bcast_lane_f64(g[2], K0 + 2), a23 = bcast_lane_f64(g[2], K0 + 3);
-		const double a33 = bcast_lane_f64(g[3], K0 + 3);
-		CHOL_STAMP(8 + 8 * gi + 1);
-		const double p0 = (a00 > 0.0) ? a00 : 1.0;       // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
-		const double y0 = rsq_newton(p0);
-		const double r0 = g[0] * y0;
-		const double l01 = a01 * y0, l02 = a02 * y0, l03 = a03 * y0;
-		const double d1 = fma(-l01, l01, a11);
-		const double p1 = (d1 > 0.0) ? d1 : 1.0;
-		const double y1 = rsq_newton(p1);
-		const double r1 = fma(-l01, r0, g[1]) * y1;
-		const double l12 = fma(-l01, l02, a12) * y1, l13 = fma(-l01, l03, a13) * y1;
-		const double d2 = fma(-l12, l12, fma(-l02, l02, a22));
-		const double p2 = (d2 > 0.0) ? d2 : 1.0;
-		const double y2 = rsq_newton(p2);
-		const double r2 = fma(-l12, r1, fma(-l02, r0, g[2])) * y2;
-		const double l23 = fma(-l12, l13, fma(-l02, l03, a23)) * y2;
-		const double d3 = fma(-l23, l23, fma(-l13, l13, fma(-l03, l03, a33)));
-		const double p3 = (d3 > 0.0) ? d3 : 1.0;
-		const double y3 = rsq_newton(p3);
-		const double r3 = fma(-l23, r2, fma(-l13, r1, fma(-l03, r0, g[3]))) * y3;
-		// (entries left of the diagonal are rounding residue here; nobody reads them: the image of R below takes j >= K only.  Rows
-		// K >= n of a ragged panel are zero rows of G: their r is zero, their pivot 1.)
-		rr[0 * 64 + j] = r0; rr[1 * 64 + j] = r1; rr[2 * 64 + j] = r2; rr[3 * 64 + j] = r3;
-		if (j == 0) {
-			pv[K0] = a00; pv[K0 + 1] = d1; pv[K0 + 2] = d2; pv[K0 + 3] = d3;
-			yinv[K0] = y0; yinv[K0 + 1] = y1; yinv[K0 + 2] = y2; yinv[K0 + 3] = y3;      // 1 / r_kk
-		}
-		CHOL_STAMP(8 + 8 * gi + 2);
-	}
-	CHOL_STAMP(8 + 8 * gi + 3);
-	lds_barrier();                                       // (LDS only: the stores of finished results stay in flight)
-	CHOL_STAMP(8 + 8 * gi + 4);
-	double rkj[4];
-#pragma unroll
-	for (int u = 0; u < 4; u++) rkj[u] = rr[u * 64 + j];
-	if (K0 + 4 < n && w == ((U + 1) & 3)) {
-		// next owner: only the four rows of its own group now (slots 0..3; after the last group of a 16-row block they are slots 4..7,
-		// which the rotation at the end of the block moves to 0..3); its other rows follow after the next barrier
-		if constexpr (U < 3) chol3_update<0, 4>(g, rr, rkj, w, kk, nlive);
-		else chol3_update<4, 8>(g, rr, rkj, w, kk, nlive);
-		deferred = true;
-		CHOL_STAMP(8 + 8 * gi + 5);
-		return;
-	}
-	if (w == U && deferred) {
-		// this group's owner still owes its rows 4.. the update of the group before (whose rows sit in the third buffer)
-		const double* rp = Rrow + ((gi + 2) % 3) * 256;
-		double rkp[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) rkp[u] = rp[u * 64 + j];
-		chol3_update<4, 16>(g, rp, rkp, w, kk, nlive);
-		deferred = false;
-	}
-	if (w == ((U + 3) & 3)) {                            // the previous owner: the finished rows go to the column-major image of R
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			const int K = K0 + u;
-			Rc[j * 65 + K] = (j >= K && K < n) ? rkj[u] : 0.0;
-		}
-	}
-	if (w <= U) chol3_update<4, 16>(g, rr, rkj, w, kk, nlive);   // (slots 0..3 of waves <= U are finished rows)
-	else chol3_update<0, 16>(g, rr, rkj, w, kk, nlive);
-	CHOL_STAMP(8 + 8 * gi + 5);
-}
-
-// one 16 x 16 x 16 block term of phase 2 for the lane (c, rg): t[r] += sum_kk X[16 xa + 4 rg + r][16 xk + kk] * Y[16 xk + kk][16 yb + c]
-// (X, Y column-major, ld 65)
-__device__ __forceinline__ void chol3_block_term(double (&t)[4], const double* X, int xa, int xk, const double* Y, int yb, int c, int rg, double sign) {
-	const double* xp = X + (16 * xk) * 65 + 16 * xa + 4 * rg;
-	const double* yp = Y + (16 * yb + c) * 65 + 16 * xk;
-#pragma unroll
-	for (int kk = 0; kk < 16; kk++) {
-		const double y = sign * yp[kk];
-#pragma unroll
-		for (int r = 0; r < 4; r++) t[r] = fma(xp[kk * 65 + r], y, t[r]);
-	}
-}
-
-template <class LOADG>
-__device__ __forceinline__ void chol_body3(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
-                                           unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
-                                           float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double** zimg_out = nullptr) {
-	__shared__ double Gs[64 * 65];               // symmetric G (assembly); afterwards Zc: Zc[k * 65 + i] = Z[i][k]
-	__shared__ double Rc[64 * 65];               // Rc[k * 65 + i] = R[i][k], zero below the diagonal
-	__shared__ double Tt[3 * 16 * 17];           // phase 2: partial block terms T of up to three waves ([wave][c][row])
-	__shared__ double Rrow[3 * 256], dg[64], pv[64], yinv[64], sred[4];
-	double* Zc = Gs;
-	if (zimg_out) *zimg_out = Zc;
-	const int t = threadIdx.x;
-	const int j = t & 63, w = t >> 6;
-	const int NP = 16 * NT;
-	CHOL_STAMP(0);
-#ifdef TSQR_CHOL_STAMPS
-	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 5] = __builtin_amdgcn_s_memrealtime();
-#endif
-	// issue the loads of G first (one value per thread and tile), then initialise LDS while they are in flight
-	double gv[10];
-	{
-		int idx = 0;
-		for (int ti = 0; ti < 4; ti++)
-			for (int tj = ti; tj < 4; tj++) {
-				if (ti < NT && tj < NT) { gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = loadg(idx * 256 + t); idx++; }
-				else gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = 0.0;
-			}
-	}
-	if (NT < 4)                                          // with all ten tiles present every entry of Gs is written below
-		for (int i = t; i < 64 * 65; i += 256) Gs[i] = 0.0;
-	for (int e = n * NP + t; e < NP * NP; e += 256) z[e] = 0.0f;          // padding rows of Z
-	__syncthreads();
-	{
-		const int reg = t >> 6, l = t & 63;
-#pragma unroll
-		for (int ti = 0; ti < 4; ti++)
-#pragma unroll
-			for (int tj = ti; tj < 4; tj++) {
-				if (ti < NT && tj < NT) {
-					// C/D layouts: f64 MFMA row = (lane>>4) + 4*reg, f32/bf16 MFMA row = 4*(lane>>4) + reg; col = lane&15
-					const int row = 16 * ti + (f32_layout ? 4 * (l >> 4) + reg : (l >> 4) + 4 * reg);
-					const int col = 16 * tj + (l & 15);
-					const double v = gv[ti * 4 + tj - (ti * (ti + 1)) / 2];
-					// a diagonal tile holds (i,j) and (j,i); in the bf16-split Gram matrix they can differ by an ulp (cross terms
-					// are added in opposite order), so only the upper-triangle owner writes both mirror positions
-					if (row <= col) {
-						Gs[row * 65 + col] = v;
-						Gs[col * 65 + row] = v;
-					}
-				}
-			}
-	}
-	__syncthreads();
-	if (shift_coef > 0.0) {                              // shifted Cholesky (Fukaya et al. 2020): G + s I, s = shift_coef * trace(G)
-		if (w == 0) {
-			double tr = (j < n) ? Gs[j * 65 + j] : 0.0;
-			for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
-			if (j < n) Gs[j * 65 + j] += shift_coef * tr;
-		}
-		__syncthreads();
-	}
-	double g[16];
-#pragma unroll
-	for (int s = 0; s < 16; s++) g[s] = Gs[(16 * (s >> 2) + 4 * w + (s & 3)) * 65 + j];
-	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; yinv[t] = 1.0; }
-	__syncthreads();                                     // (every wave has its rows: Gs may be reused as Zc from here on)
-	// ---- phase 1: elimination ----
-	bool deferred = false;
-	CHOL_STAMP(1);
-#pragma unroll 1
-	for (int kk = 0; kk < 4; kk++) {
-		static_for<0, 4>([&](auto u) { chol3_group<decltype(u)::value>(g, Rrow, Rc, pv, yinv, w, j, n, kk, deferred); });
-#pragma unroll
-		for (int s = 0; s < 12; s++) g[s] = g[s + 4];    // the next 16-row block moves to slots 0..3
-	}
-	// ragged n: the rows of the groups that were skipped are zero rows of the image of R with a unit pivot (yinv = 1), so that phase 2
-	// needs no special cases
-	for (int K = 4 * ((n + 3) / 4) + w; K < 64; K += 4) Rc[j * 65 + K] = 0.0;
-	CHOL_STAMP(2);
-	lds_barrier();
-	// R out now (fp32, exact zeros below the diagonal): its stores overlap phase 2
-	{
-		const int i = t & 63;
-		if (i < n)
-			for (int jj = t >> 6; jj < n; jj += 4) r[(size_t)jj * ldr + i] = (float)Rc[jj * 65 + i];
-	}
-	// ---- phase 2: Z = inverse(R) by 16 x 16 blocks ----
-	const int c = j & 15, rg = j >> 4;
-	{
-		// diagonal blocks: wave a inverts R_aa by back substitution, lane c (of every lane row: four identical copies, lane row 0
-		// stores) owns column c:  z_i = (delta_ic - sum_{k > i} r_ik z_k) / r_ii
-		const int a = w;
-		double zc[16];
-#pragma unroll
-		for (int i = 15; i >= 0; i--) {
-			double sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-			for (int k = i + 1; k < 16; k++) sacc = fma(-Rc[(16 * a + k) * 65 + 16 * a + i], zc[k], sacc);
-			zc[i] = sacc * yinv[16 * a + i];
-		}
-		if (rg == 0) {
-#pragma unroll
-			for (int i = 0; i < 16; i++) Zc[(16 * a + c) * 65 + 16 * a + i] = zc[i];
-		}
-		// the blocks below the block diagonal are zero
-		for (int b = 0; b < a; b++)
-			for (int i = rg; i < 16; i += 4) Zc[(16 * b + c) * 65 + 16 * a + i] = 0.0;
-	}
-	lds_barrier();
-#pragma unroll 1
-	for (int d = 1; d < 4; d++) {
-		// block diagonal d: Z_ab = -Z_aa T, T = sum_{k = a+1 .. b} R_ak Z_kb, b = a + d.  The d terms of every T are spread over the
-		// waves (unit u = pair * d + term -> wave u % 4, at most two rounds), partial T through LDS, then one wave per pair finishes.
-		const int npairs = 4 - d, nunits = npairs * d;
-		double tacc[4] = {0.0, 0.0, 0.0, 0.0};
-		for (int u = w; u < nunits; u += 4) {            // (nunits <= 4 except d = 2: 4 units; d = 3: 3 units; d = 1: 3 units)
-			const int pair = u / d, term = u % d;
-			const int a = pair, b = pair + d, k = a + 1 + term;
-			double tt[4] = {0.0, 0.0, 0.0, 0.0};
-			chol3_block_term(tt, Rc, a, k, Zc, b, c, rg, 1.0);
-			if (term == 0) {
-#pragma unroll
-				for (int r2 = 0; r2 < 4; r2++) tacc[r2] = tt[r2];
-			} else {
-#pragma unroll
-				for (int r2 = 0; r2 < 4; r2++) Tt[((pair * 2 + term - 1) * 16 + c) * 17 + 4 * rg + r2] = tt[r2];   // (d = 2: slots 0, 2; d = 3: slots 0, 1)
-			}
-		}
-		lds_barrier();
-		// the wave that computed term 0 of a pair owns the pair: add the other terms, exchange T through LDS (a lane needs the whole
-		// column c of T for the second product), finish
-		if (w < nunits && (w % d) == 0 && (w / d) < npairs) {
-			const int pair = w / d, a = pair, b = pair + d;
-			for (int term = 1; term < d; term++)
-#pragma unroll
-				for (int r2 = 0; r2 < 4; r2++) tacc[r2] += Tt[((pair * 2 + term - 1) * 16 + c) * 17 + 4 * rg + r2];
-			double* Tw = Tt + (d == 1 ? pair : pair * 2) * 16 * 17;   // exchange slot of the pair for the summed T (column c, 16 rows; for
-			                                                          // d >= 2 it held the pair's term 1, read above by the same lanes)
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int r2 = 0; r2 < 4; r2++) Tw[c * 17 + 4 * rg + r2] = tacc[r2];
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-			__builtin_amdgcn_wave_barrier();
-			double zo[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-			for (int k2 = 0; k2 < 16; k2++) {
-				const double tk = -Tw[c * 17 + k2];
-#pragma unroll
-				for (int r2 = 0; r2 < 4; r2++) zo[r2] = fma(Zc[(16 * a + k2) * 65 + 16 * a + 4 * rg + r2], tk, zo[r2]);
-			}
-#pragma unroll
-			for (int r2 = 0; r2 < 4; r2++) Zc[(16 * b + c) * 65 + 16 * a + 4 * rg + r2] = zo[r2];
-		}
-		lds_barrier();
-	}
-	CHOL_STAMP(6);
-	// ---- phase 3: verdict and the fp32 image of Z ----
-	// scaled conditioning S = || D * inverse(R) ||_F^2 / n with D = diag(sqrt(g_jj)); status words as in chol_body
-	double s_acc = 0.0;
-	for (int K = w; K < n; K += 4) {
-		const double zv = (j <= K) ? Zc[K * 65 + j] : 0.0;   // Z[j][K]
-		if (j < NP) z[(size_t)K * NP + j] = (float)zv;
-		if (j < n) s_acc = fma(dg[j] * zv, zv, s_acc);
-	}
-	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
-	if (j == 0) sred[w] = s_acc;
-	lds_barrier();
-	if (w == 0) {
-		const double d0 = dg[j], p0 = pv[j];
-		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
-		if (j < n && !(d0 >= min_diag)) ratio = 0.0f;    // (bf16-split level: column norms in the fp32 denormal product range)
-		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
-		if (j == 0) {
-			const float scond = (float)(((sred[0] + sred[1]) + (sred[2] + sred[3])) / (double)n);
-			const unsigned s0 = (ratio > min_ratio && scond <= max_scond) ? 0u : 1u;     // NaN compares false -> rejected
-			status[0] = s0;
-			status[1] = __builtin_bit_cast(unsigned, ratio);
-			status[2] = __builtin_bit_cast(unsigned, scond);
-			if (host_status) {
-				volatile unsigned* hs = host_status;
-				hs[1] = __builtin_bit_cast(unsigned, ratio);
-				hs[2] = __builtin_bit_cast(unsigned, scond);
-				hs[0] = s0;
-			}
-		}
-	}
-	CHOL_STAMP(3);
-#ifdef TSQR_CHOL_STAMPS
-	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 4] = __builtin_amdgcn_s_memrealtime();
-	__syncthreads();
-	if (g_chol_stamp_out)
-		for (int i = threadIdx.x; i < 4 * CHOL_NSTAMP; i += 256) g_chol_stamp_out[i] = chol_stamp_lds[i];
-#endif
-}
-
 struct CholArgs {
 	float* r; size_t ldr;                // R out: n x n, full block written (zeros below the diagonal)
 	float* z;                            // Z = inverse(R) out: NP x NP column-major (ld NP), zero padded
@@ -1539,8 +1109,6 @@ struct CholArgs {
 	float scond_floor;                   // bf16 level: S <= min(128, max(scond_floor, 0.12 sqrt(rows)))
 };
 
-// VAR: 0 chol_body (round 2), 1 chol_body with chol_group2, 2 chol_body3 (round 3: the product's)
-template <int VAR = 2>
 __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 	// prev_status: status word of an earlier factorisation this one depends on (speculatively enqueued second sweep): when that one
 	// was rejected this one reports "rejected" at once, so that everything enqueued behind it skips as well
@@ -1563,93 +1131,8 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 	} else {
 		shift = a.shift_coef * (rows * (double)a.n + (double)a.n * (double)(a.n + 1));
 	}
-	if constexpr (VAR == 2)
-		chol_body3(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
-		           shift, min_diag);
-	else
-		chol_body<VAR == 1>(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
-		                    shift, min_diag);
-}
-
-// gram_reduce_chol_kernel: the reduction of the per-workgroup Gram partials AND the Cholesky step in one launch (single-GPU calls:
-// a row-partitioned call has an all-reduce between the two and keeps gram_reduce1_kernel + chol_kernel).  The grid is the
-// reduction's (16 entries per workgroup); every workgroup writes its 16 sums with write-through (sc1) stores, drains them and takes
-// a ticket with one agent-scope atomic add; the workgroup whose add returns the last ticket reads the summed tiles back with sc1
-// loads and runs chol_body -- the "last adder" hand-off of MI355X_MICROARCH.md (workgroup dispatch / inter-workgroup visibility:
-// sc1 stores + vmcnt(0) + barrier + one atomic add per workgroup; the last adder loads only after its add has returned, its other
-// waves behind a barrier).  Saves a kernel boundary and the Cholesky launch's own ramp (~3 us of the 2^20 x 64 call).
-struct ReduceCholArgs {
-	CholArgs ch;                         // ch.gsum: summed tiles (written here, then read by the last workgroup)
-	const double* part; int nparts; int nelem;
-	unsigned* ticket;                    // arrival counter: zero at launch (GramArgs::ticket_zero), reset to zero by the last workgroup
-};
-template <int VAR = 2>
-__global__ __launch_bounds__(256) void gram_reduce_chol_kernel(const ReduceCholArgs a) {
-	if (a.ch.prev_status && a.ch.prev_status[0] != 0) {      // (uniform over the grid: nobody takes a ticket)
-		if (blockIdx.x == 0 && threadIdx.x == 0) {
-			a.ch.status[0] = 1u; a.ch.status[1] = 0u; a.ch.status[2] = 0u;
-			if (a.ch.host_status) { volatile unsigned* hs = a.ch.host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
-		}
-		return;
-	}
-	double* gout = const_cast<double*>(a.ch.gsum);
-	const int nelem = a.nelem, nparts = a.nparts;
-	const double* __restrict__ part = a.part;
-	if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&gout[nelem], a.ch.rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	__shared__ double red[16][17];
-	__shared__ unsigned last_wg;
-	const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
-	const int el = blockIdx.x * 16 + e;
-	double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-	if (el < nelem) {                                        // (same partition and summation order as gram_reduce1_kernel)
-		double v[32];
-#pragma unroll
-		for (int u = 0; u < 32; u++) {
-			const int b = sg + 16 * u;
-			v[u] = part_load(&part[(size_t)min(b, nparts - 1) * nelem + el]);
-		}
-#pragma unroll
-		for (int u = 0; u < 32; u++)
-			if (sg + 16 * u >= nparts) v[u] = 0.0;
-#pragma unroll
-		for (int i = 0; i < 8; i++) { s0 += v[4 * i]; s1 += v[4 * i + 1]; s2 += v[4 * i + 2]; s3 += v[4 * i + 3]; }
-		for (int b = sg + 512; b < nparts; b += 16) s0 += part_load(&part[(size_t)b * nelem + el]);
-	}
-	red[sg][e] = (s0 + s1) + (s2 + s3);
-	__syncthreads();
-	if (sg == 0 && el < nelem) {
-		double v[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) v[k] = red[k][e];
-		const double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
-		                   (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
-		__hip_atomic_store(&gout[el], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1)
-	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its stores ...
-	__syncthreads();                                         // ... before the one lane that signals for the workgroup
-	if (threadIdx.x == 0) {
-		const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const unsigned last = (old == gridDim.x - 1) ? 1u : 0u;
-		if (last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next counted launch
-		last_wg = last;
-	}
-	__syncthreads();                                         // the last adder's other waves load behind this barrier
-	if (!last_wg) return;
-	const CholArgs& c = a.ch;
-	float min_ratio = 0.0f, max_scond = INFINITY;
-	double min_diag = 0.0, shift = 0.0;
-	if (c.level == 2) {
-		min_ratio = 0.03125f;
-		max_scond = fminf(128.0f, fmaxf(c.scond_floor, 0.12f * sqrtf((float)c.rows)));
-		min_diag = c.rows * 0x1p-90;
-	} else if (c.level == 1) {
-		min_ratio = 9.094947017729282e-13f;              // 2^-40
-	} else {
-		shift = c.shift_coef * (c.rows * (double)c.n + (double)c.n * (double)(c.n + 1));
-	}
-	auto loadg = [&](int e2) { return __hip_atomic_load(&c.gsum[e2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // sc1: L2, never a stale L1 line
-	if constexpr (VAR == 2) chol_body3(c.r, c.ldr, c.z, c.status, c.host_status, loadg, c.n, c.NT, c.level == 2 ? 1 : 0, min_ratio, max_scond, shift, min_diag);
-	else chol_body<VAR == 1>(c.r, c.ldr, c.z, c.status, c.host_status, loadg, c.n, c.NT, c.level == 2 ? 1 : 0, min_ratio, max_scond, shift, min_diag);
+	chol_body(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
+	          shift, min_diag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2290,45 +1773,6 @@ __global__ __launch_bounds__(256) void rmul_kernel(float* __restrict__ r, size_t
 			for (int k = i; k <= j; k++) acc += (double)r2[(size_t)k * ldr2 + i] * (double)r1[(size_t)j * ldr1 + k];
 		r[(size_t)j * ldr + i] = (float)acc;
 	}
-}
-
-// The same product for large n (the reference's own sweep goes to n = m = 2^15): 32 x 32 output tiles, k-tiles between the two
-// diagonals only, operands staged through LDS in fp64, 2 x 2 outputs per thread.  The naive kernel above needs 90 ms at n = 4096.
-__global__ __launch_bounds__(256) void rmul_tiled_kernel(float* __restrict__ r, size_t ldr, const float* __restrict__ r2, size_t ldr2,
-                                                         const float* __restrict__ r1, size_t ldr1, int n) {
-	__shared__ double As[32][33], Bs[32][33];            // As[i][k] = R2[i0+i][k0+k], Bs[k][j] = R1[k0+k][j0+j]
-	const int ti = blockIdx.y, tj = blockIdx.x;
-	const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-	const int i0 = 32 * ti, j0 = 32 * tj;
-	double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-	if (ti <= tj) {                                      // uniform per workgroup
-		for (int tk = ti; tk <= tj; tk++) {
-			const int k0 = 32 * tk;
-			for (int e = threadIdx.x; e < 32 * 32; e += 256) {
-				const int a = e & 31, b = e >> 5;            // a runs along the contiguous (row) index of the column-major sources
-				const int gi = i0 + a, gk = k0 + b;          // R2[gi][gk]
-				As[a][b] = (gi < n && gk < n && gi <= gk) ? (double)r2[(size_t)gk * ldr2 + gi] : 0.0;
-				const int gk2 = k0 + a, gj = j0 + b;         // R1[gk2][gj]
-				Bs[a][b] = (gk2 < n && gj < n && gk2 <= gj) ? (double)r1[(size_t)gj * ldr1 + gk2] : 0.0;
-			}
-			__syncthreads();
-#pragma unroll 8
-			for (int k = 0; k < 32; k++) {
-				const double a0 = As[ty][k], a1 = As[ty + 16][k];
-				const double b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
-				acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
-				acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
-			}
-			__syncthreads();
-		}
-	}
-#pragma unroll
-	for (int a = 0; a < 2; a++)
-#pragma unroll
-		for (int b = 0; b < 2; b++) {
-			const int gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
-			if (gi < n && gj < n) r[(size_t)gj * ldr + gi] = (gi <= gj) ? (float)acc[a][b] : 0.0f;
-		}
 }
 
 // completion signal: one thread stores seq to device-visible pinned host memory.  Enqueued behind the last kernel of a call

@@ -44,23 +44,12 @@ struct Settings {
 	std::atomic<int> policy{0};          // 0 auto, 1 Householder, 2 Gram without check/fallback
 	std::atomic<int> gram_level{2};      // first Gram level tried: 2 bf16-split (then fp64), 1 fp64 only
 	std::atomic<int> level0_waves{2048}, tree_cpw{4}, gram_waves{2048};
-	std::atomic<int> wide{1};                            // 64 < n <= 128: one Cholesky-QR panel of up to 128 columns first (policy 5 turns it off)
-	std::atomic<int> apply_wgs{env_int("TSQR_MI_APPLY_WGS", 0)};        // 0: as many workgroups as are resident at once
-	std::atomic<int> apply_rows{env_int("TSQR_MI_APPLY_ROWS", 0)};      // rows per workgroup block of apply_wg_kernel: 64 / 128 / 256, 0 = auto
-	                                                                    // (bf16x3 engine: 64 rows, four workgroups per CU and two blocks in flight
-	                                                                    //  each -- 88 vs 92 us at 2^20 x 64, 881 vs 940 us at 2^23 x 64; else 128)
+	std::atomic<int> wide{1};            // 64 < n <= 128: one Cholesky-QR panel of up to 128 columns first (policy 5 turns it off)
+	std::atomic<int> apply_wgs{0};       // workgroups of the apply pass; 0: as many as are resident at once (tsqr_mi_set_tuning2)
+	// the two environment switches that are left (read once at load): the floor of the bf16-split level's bound on the scaled
+	// conditioning S, and a diagnostic print of every Cholesky verdict
 	const float bf16_scond_floor = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);
 	const int debug = env_int("TSQR_MI_DEBUG", 0);
-	const int host_status = env_int("TSQR_MI_HOST_STATUS", 1);   // Cholesky status words written straight into pinned host memory
-	const int host_flag = env_int("TSQR_MI_HOST_FLAG", 1);       // end of call: spin on a pinned flag word instead of hipStreamSynchronize
-	const int shifted = env_int("TSQR_MI_SHIFTED", 1);           // shifted Cholesky QR (two-step) before the Householder fallback
-	const int fuse_gramq = env_int("TSQR_MI_FUSE_GRAMQ", 1);     // reorth, n <= 64: the first sweep's apply kernel also accumulates Q^T Q
-	const int spec_reorth = env_int("TSQR_MI_SPEC_REORTH", 1);   // reorth, n <= 64: both sweeps enqueued speculatively
-	const int auto_sweep2 = env_int("TSQR_MI_AUTO_SWEEP2", 1);   // n <= 16 without reorth: second sweep when the first one is ill conditioned
-	const int fold_tree = env_int("TSQR_MI_FOLD_TREE", 1);       // Householder engine, 64-column panels: collapsed R-stack tree (fold_tree_kernel)
-	const int fold_cor = env_int("TSQR_MI_FOLD_COR", 1);         // Householder engine, fp32_tc_cor: error-corrected bf16x3 MFMA block reflectors
-	const int chol_var = env_int("TSQR_MI_CHOL_VAR", 0);         // Cholesky step: 0 round-2 chol_body, 1 + chol_group2, 2 chol_body3
-	const int merge_chol = env_int("TSQR_MI_MERGE_CHOL", 1);     // single-GPU calls: Gram reduction + Cholesky in one launch (gram_reduce_chol_kernel)
 };
 Settings g_set;
 std::atomic<unsigned> g_seq{0};                        // sequence numbers of the completion flags (any thread)
@@ -266,9 +255,6 @@ struct Ctx {
 	double* gramq_part = nullptr;                        // non-null: apply launches write per-workgroup Gram partials of their output there
 	int gramq_cap = 0, gramq_nparts = 0;
 	bool gramq_ready = false;                            // the next bf16-level Gram request can skip its pass (partials are in place)
-	const double* pend_part = nullptr;                   // per-workgroup Gram partials whose reduction is still to be enqueued: the next
-	int pend_nparts = 0, pend_nelem = 0;                 // chol_from_g sums them and factors in ONE launch (gram_reduce_chol_kernel)
-	unsigned* ticket() const { return reinterpret_cast<unsigned*>(wq + L.status) + 15; }   // (word 15 of status slot 0: slots use words 0..2)
 	Comm comm;
 	bool fold_cor = false;                               // Householder engine: block reflectors on the error-corrected bf16x3 MFMA (fp32_tc_cor)
 	double rows_global = 0.0;                            // host's view of the global row count (the device thresholds of a row-partitioned
@@ -300,7 +286,6 @@ struct HostSigCache { unsigned* h_wl = nullptr; unsigned* dev = nullptr; };
 thread_local HostSigCache t_hsig_cache;
 void resolve_host_sig(Ctx& c, unsigned* h_wl, size_t m) {
 	c.hsig = HostSig{};
-	if (!g_set.host_status) return;
 	if (h_wl && ref_bs(m) + 1 >= 8) {
 		if (t_hsig_cache.h_wl == h_wl) { c.hsig.host = h_wl; c.hsig.dev = t_hsig_cache.dev; return; }
 		hipPointerAttribute_t at{};
@@ -318,7 +303,7 @@ void resolve_host_sig(Ctx& c, unsigned* h_wl, size_t m) {
 // it (about 5 us cheaper than hipStreamSynchronize, tools/launch_cost.py, and free of its sporadic OS wake-up stalls) and polls
 // the stream now and then so that a failed launch cannot hang the caller.  Returns 1 when the flag path is not available.
 int signal_and_wait(Ctx& c) {
-	if (!g_set.host_flag || !c.hsig.dev || t_prof.on) return 1;
+	if (!c.hsig.dev || t_prof.on) return 1;
 	unsigned seq = ++g_seq;
 	if (seq == 0) seq = ++g_seq;
 	volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c.hsig.host) + 3;
@@ -395,15 +380,14 @@ int dispatch_fold(int NT, const tsqrmi::FoldArgs& a, hipStream_t st) {
 	}
 }
 
-// the collapsed R-stack tree (fold_tree_kernel): nblocks upper-triangular 64 x 64 blocks of `stack` -> R, ping-ponging between
-// `stack` and `other`; every launch reduces by up to FOLD_TREE_WAVES * per_wave per workgroup
-int fold_tree(Ctx& c, float* r, size_t ldr, float* stack, size_t stack_ld, int nblocks, size_t n, float* other, bool cor) {
-	constexpr int RP = (64 * 65) / 2 + 16;
-	constexpr int W = tsqrmi::FOLD_TREE_WAVES;
-	constexpr int lds = (W * RP + W * 256) * (int)sizeof(float);
+// the R-stack reduction (fold_coop_kernel): nblocks upper-triangular 64 x 64 blocks of `stack` -> R, ping-ponging between `stack` and
+// `other`; eight stacked blocks per workgroup and 64-step chain: 2048 -> 256 -> 32 -> 4 -> 1 in four launches / four dependent chains
+int fold_coop(Ctx& c, float* r, size_t ldr, float* stack, size_t stack_ld, int nblocks, size_t n, float* other, bool cor) {
+	constexpr int W = tsqrmi::FOLD_COOP_WAVES;
+	constexpr int lds = tsqrmi::FOLD_COOP_LDS_FLOATS * (int)sizeof(float);
 	static DevOnce attr[2];
 	if (attr[cor].need(c.dev)) {
-		HIPCHK(hipFuncSetAttribute(cor ? reinterpret_cast<const void*>(&tsqrmi::fold_tree_kernel<true>) : reinterpret_cast<const void*>(&tsqrmi::fold_tree_kernel<false>),
+		HIPCHK(hipFuncSetAttribute(cor ? reinterpret_cast<const void*>(&tsqrmi::fold_coop_kernel<true>) : reinterpret_cast<const void*>(&tsqrmi::fold_coop_kernel<false>),
 		                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 		attr[cor].done(c.dev);
 	}
@@ -412,15 +396,13 @@ int fold_tree(Ctx& c, float* r, size_t ldr, float* stack, size_t stack_ld, int n
 	for (;;) {
 		tsqrmi::FoldTreeArgs a{};
 		a.src = cur; a.ld = cur_ld; a.nblocks = nblocks; a.n = (int)n;
-		int wgs;
-		if (nblocks <= W * 2) { a.per_wave = (nblocks + W - 1) / W; wgs = 1; }
-		else { a.per_wave = 2; wgs = (nblocks + 2 * W - 1) / (2 * W); }
+		const int wgs = (nblocks + W - 1) / W;
 		if (wgs == 1) { a.dst = r; a.dst_ld = ldr; a.rows_store = (int)n; a.cols_store = (int)n; }
 		else { a.dst = nxt; a.dst_ld = (size_t)wgs * 64; a.rows_store = 64; a.cols_store = 64; }
 		{
 			ProfScope ps(KC_TREE, c.st);
-			if (cor) hipLaunchKernelGGL(tsqrmi::fold_tree_kernel<true>, dim3(wgs), dim3(64 * W), lds, c.st, a);
-			else hipLaunchKernelGGL(tsqrmi::fold_tree_kernel<false>, dim3(wgs), dim3(64 * W), lds, c.st, a);
+			if (cor) hipLaunchKernelGGL(tsqrmi::fold_coop_kernel<true>, dim3(wgs), dim3(64 * W), lds, c.st, a);
+			else hipLaunchKernelGGL(tsqrmi::fold_coop_kernel<false>, dim3(wgs), dim3(64 * W), lds, c.st, a);
 		}
 		HIPCHK(hipGetLastError());
 		if (wgs == 1) break;
@@ -456,9 +438,9 @@ int fold_r(Ctx& c, float* r, size_t ldr, const float* src, size_t ld, size_t m, 
 			dispatch_fold(NT, a, c.st);
 		}
 		HIPCHK(hipGetLastError());
-		if (lv == 0 && p.nw[0] > 1 && p.NP == 64 && g_set.fold_tree) {
-			// 64-column panels: the whole R-stack tree in one or two launches (fold_tree_kernel) instead of one launch per level
-			return fold_tree(c, r, ldr, stack_a, (size_t)p.nw[0] * 64, p.nw[0], n, stack_b, cor);
+		if (lv == 0 && p.nw[0] > 1 && p.NP == 64) {
+			// 64-column panels: the whole R-stack reduction by cooperative eight-block folds (fold_coop_kernel) instead of one launch per binary level
+			return fold_coop(c, r, ldr, stack_a, (size_t)p.nw[0] * 64, p.nw[0], n, stack_b, cor);
 		}
 	}
 	return 0;
@@ -471,16 +453,13 @@ template <int NT> void launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool 
 
 // Gram matrix of src (m x n) in MFMA-accumulator order -> c.gsum() (ntri*256 doubles + the local row count behind them), summed
 // over the ranks of a row-partitioned call.  bf16 = true: bf16x3-split MFMA (memory-bound, f32 C/D layout), false: fp64 MFMA.
-// reduce_now = false (single-GPU ladder): the partials stay pending and the NEXT chol_from_g sums and factors them in one launch.
-int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16, bool reduce_now = true) {
+int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16) {
 	const GramPlan g = gram_plan(m, n);
 	const int NT = (int)(np_of(n) / 16);
 	tsqrmi::GramArgs a{};
 	a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
 	a.part = reinterpret_cast<double*>(c.wr);
 	a.skip_status = c.prev_slot >= 0 ? c.status_dev(c.prev_slot) : nullptr;
-	a.ticket_zero = c.ticket();
-	c.pend_part = nullptr;
 	int nparts = g.nblocks;                              // workgroups that wrote a partial
 	if (bf16 && c.gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		c.gramq_ready = false;
@@ -496,10 +475,6 @@ int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16, b
 	}
 	HIPCHK(hipGetLastError());
 	const int nelem = g.ntri * 256;
-	if (!reduce_now && !c.comm.active() && g_set.merge_chol) {
-		c.pend_part = a.part; c.pend_nparts = nparts; c.pend_nelem = nelem;
-		return 0;
-	}
 	{
 		ProfScope ps(KC_CHOL, c.st);
 		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), a.part, nparts, nelem, (double)m);
@@ -527,21 +502,9 @@ int chol_from_g(Ctx& c, float* r, size_t ldr, size_t n, int level) {
 	a.rows = c.rows_global;
 	a.shift_coef = (level == 3) ? 11.0 * 1.1102230246251565e-16 : 0.0;
 	a.n = (int)n; a.NT = NT; a.level = level; a.scond_floor = g_set.bf16_scond_floor;
-	if (c.pend_part) {
-		// the Gram pass just enqueued left its partials unreduced: reduction + Cholesky in one launch (last-arriving workgroup factors)
-		tsqrmi::ReduceCholArgs ra{};
-		ra.ch = a; ra.part = c.pend_part; ra.nparts = c.pend_nparts; ra.nelem = c.pend_nelem; ra.ticket = c.ticket();
-		c.pend_part = nullptr;
+	{
 		ProfScope ps(KC_CHOL, c.st);
-		const dim3 grid((ra.nelem + 15) / 16);
-		if (g_set.chol_var == 2) hipLaunchKernelGGL(tsqrmi::gram_reduce_chol_kernel<2>, grid, dim3(256), 0, c.st, ra);
-		else if (g_set.chol_var == 1) hipLaunchKernelGGL(tsqrmi::gram_reduce_chol_kernel<1>, grid, dim3(256), 0, c.st, ra);
-		else hipLaunchKernelGGL(tsqrmi::gram_reduce_chol_kernel<0>, grid, dim3(256), 0, c.st, ra);
-	} else {
-		ProfScope ps(KC_CHOL, c.st);
-		if (g_set.chol_var == 2) hipLaunchKernelGGL(tsqrmi::chol_kernel<2>, dim3(1), dim3(256), 0, c.st, a);
-		else if (g_set.chol_var == 1) hipLaunchKernelGGL(tsqrmi::chol_kernel<1>, dim3(1), dim3(256), 0, c.st, a);
-		else hipLaunchKernelGGL(tsqrmi::chol_kernel<0>, dim3(1), dim3(256), 0, c.st, a);
+		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, a);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -590,11 +553,11 @@ template <int E, int NT, bool UPD> int launch_apply_any(Ctx& c, const tsqrmi::Ap
 	if constexpr (!UPD && E != 0) {                      // (the fp32-MFMA engine's fused variant spills and loses: 0.29 vs 0.22 ms per apply)
 		if (c.gramq_part && c.gramq_cap > 0) return launch_apply_wg<E, NT, UPD, 128, true>(c, a);
 	}
-	const int rows = g_set.apply_rows.load();
-	if (rows == 256) return launch_apply_wg<E, NT, UPD, 256>(c, a);
-	if constexpr (!UPD && E == 1) { if (rows == 64 || rows == 0) return launch_apply_wg<E, NT, UPD, 64>(c, a); }
-	if constexpr (!UPD && E == 0) { if (rows == 64) return launch_apply_wg<E, NT, UPD, 64>(c, a); }
-	return launch_apply_wg<E, NT, UPD, 128>(c, a);
+	// block height per engine (measured, profiles/r02_experiment_log.md): the bf16x3 engine streams best with 64-row blocks, four
+	// workgroups per CU and two blocks in flight (88 vs 92 us at 2^20 x 64); the exact-fp32 and fp16 engines and the coupling
+	// update (UPD) use 128-row blocks
+	if constexpr (!UPD && E == 1) return launch_apply_wg<E, NT, UPD, 64>(c, a);
+	else return launch_apply_wg<E, NT, UPD, 128>(c, a);
 }
 template <int E> int dispatch_apply_nt(Ctx& c, int NT, const tsqrmi::ApplyArgs& a) {
 	switch (NT) {
@@ -637,13 +600,8 @@ int engine_of(int mode) {
 
 // r <- r2 * r1 (upper triangular n x n, fp64 accumulation; r may not alias r1 / r2)
 void launch_rmul(float* r, size_t ldr, const float* r2, size_t ldr2, const float* r1, size_t ldr1, size_t n, hipStream_t st) {
-	if (n > 128) {
-		const unsigned t = (unsigned)cdiv(n, 32);
-		hipLaunchKernelGGL(tsqrmi::rmul_tiled_kernel, dim3(t, t), dim3(256), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
-	} else {
-		const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
-		hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
-	}
+	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
+	hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
 }
 
 // Householder TSQR R factor of one <= 64-column panel.  Row-partitioned: every rank folds its block, the n x n factors are
@@ -682,7 +640,7 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 	const bool direct_shift = (r_engine == R_SHIFT_DIRECT);
 	if (direct_shift) r_engine = 0;
 	for (int e = r_engine; e >= 1; e--) {                // 2: bf16-split Gram, 1: fp64 Gram; with check_now a rejected level escalates
-		rc = gram_g(c, ap, lda, m, cc, e == 2, /*reduce_now=*/false);
+		rc = gram_g(c, ap, lda, m, cc, e == 2);
 		if (rc) return rc;
 		rc = chol_from_g(c, rpp, ldr, cc, e);
 		if (rc) return rc;
@@ -700,7 +658,7 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 			return apply_rinv(c, engine, qp, ldq, ap, lda, rpp, ldr, m, cc, /*z_ready=*/true, skip);
 		}
 	}
-	if ((direct_shift || (r_engine >= 1 && check_now)) && g_set.shifted && c.policy == 0) {
+	if ((direct_shift || (r_engine >= 1 && check_now)) && c.policy == 0) {
 		// Both Gram levels rejected the panel (cond beyond ~1e6, or rank deficient).  Shifted Cholesky QR: the fp64 Gram matrix is
 		// still in the work buffer; R1 = chol(G + s I) always exists, Q1 = A inverse(R1) has cond(Q1) <~ 1e5, and one unshifted fp64
 		// sweep on Q1 in place finishes the panel: A = Q (R2 R1).  About 2x faster than the Householder fold below and, after that
@@ -714,7 +672,7 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 		if (status == 0) {
 			rc = apply_rinv(c, engine, qp, ldq, ap, lda, r1, cc, m, cc, /*z_ready=*/true);
 			if (rc) return rc;
-			rc = gram_g(c, qp, ldq, m, cc, /*bf16=*/false, /*reduce_now=*/false);
+			rc = gram_g(c, qp, ldq, m, cc, /*bf16=*/false);
 			if (rc) return rc;
 			rc = chol_from_g(c, r2, cc, cc, 1);
 			if (rc) return rc;
@@ -880,7 +838,7 @@ int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, c
 // ---------------------------------------------------------------------------------------------------------------------------
 int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n) {
 	const WqLayout& L = c.L;
-	c.fold_cor = (engine == 1) && g_set.fold_cor;
+	c.fold_cor = (engine == 1);
 	// auto policy: every mode starts at the bf16-split Gram level (exact products, fp64 accumulation across K-steps: more accurate
 	// than any plain fp32 evaluation of A^T A, accepted only for well-conditioned panels), then the fp64 Gram level, the shifted
 	// Cholesky QR step and the Householder fold; the mode selects the MFMA engine of the apply pass.  Policy 4 skips the bf16 level.
@@ -930,7 +888,7 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 		if (!reorth) {
 			// level 0 reached in the speculative (deferred) mode: both Gram levels were rejected and the fp64 Gram matrix of A is
 			// still in the work buffer: panel_qr takes the shifted-Cholesky path on it before the Householder fold
-			const bool retry_checked = (level == 0 && deferred && g_set.shifted && first_level >= 1);
+			const bool retry_checked = (level == 0 && deferred && first_level >= 1);
 			rc = sweep(c, engine, retry_checked ? R_SHIFT_DIRECT : level, check_now || retry_checked, q, ldq, r, ldr, a, lda, m, n);
 			if (rc) return rc;
 			if (n > PW) hipLaunchKernelGGL(tsqrmi::zero_lower_kernel, dim3(gb), dim3(256), 0, c.st, r, ldr, (int)n);
@@ -941,8 +899,8 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 			float* r1 = c.wq + L.r1; float* r2 = c.wq + L.r2;
 			// single panel: the first sweep's (last) apply launch accumulates Q^T Q while the block is in LDS, so that the second
 			// sweep's bf16-level Gram pass over Q is not needed
-			const bool fuse = g_set.fuse_gramq && n <= PW && c.policy == 0 && level == 2;
-			if (g_set.spec_reorth && n <= PW && c.policy == 0 && level == first_level && !t_prof.on) {
+			const bool fuse = n <= PW && c.policy == 0 && level == 2;
+			if (n <= PW && c.policy == 0 && level == first_level && !t_prof.on) {
 				// Optimistic attempt: both sweeps, the R product and the completion flag are enqueued without looking at a verdict.
 				// Device-side chain: apply 1 skips when Cholesky 1 rejected; Cholesky 2 then reports "rejected" at once; apply 2 (in
 				// place) skips when Cholesky 2 rejected -- so A stays intact and Q holds Q1 or garbage, never a half-applied state.
@@ -981,7 +939,7 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 				}
 				level = std::max(level - 1, 0);              // first sweep rejected at this level: checked path from the next one
 			}
-			const bool fuse2 = g_set.fuse_gramq && n <= PW && c.policy == 0 && first_level == 2;
+			const bool fuse2 = n <= PW && c.policy == 0 && first_level == 2;
 			if (fuse2) { c.gramq_part = reinterpret_cast<double*>(c.wr); c.gramq_cap = gram_plan(m, n).nblocks; c.gramq_nparts = 0; }
 			rc = sweep(c, engine, level, check_now, q, ldq, r1, n, a, lda, m, n);
 			c.gramq_part = nullptr; c.gramq_cap = 0;
@@ -1007,7 +965,7 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 	// n <= 16 without reorthogonalisation: the reference's tsqr16 builds Q from its Householder tree and stays O(eps) orthogonal at
 	// any conditioning, while Q = A * inverse(R) loses orthogonality like cond * eps.  When the accepted sweep reports a scaled
 	// conditioning beyond 32 (measured loss ~ 3.6e-7 * sqrt(S)), a second sweep on Q in place restores O(eps): R <- R2 * R.
-	if (!reorth && deferred && n <= 16 && g_set.auto_sweep2 && c.min_level >= 1 && !c.used_shift && !c.used_householder && scond1 > 32.0f) {
+	if (!reorth && deferred && n <= 16 && c.min_level >= 1 && !c.used_shift && !c.used_householder && scond1 > 32.0f) {
 		float* r1 = c.wq + L.r1; float* r2 = c.wq + L.r2;
 		hipLaunchKernelGGL(tsqrmi::copy2d_kernel, dim3(gb), dim3(256), 0, c.st, r1, n, r, ldr, (int)n, (int)n);
 		HIPCHK(hipGetLastError());
