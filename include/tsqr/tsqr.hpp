@@ -33,7 +33,11 @@ enum compute_mode {
 inline std::size_t get_batch_size_log2(const std::size_t m) { return tsqr_mi_batch_size_log2(m); }
 inline std::size_t get_batch_size(const std::size_t m) { return tsqr_mi_batch_size(m); }
 
-// every mode this engine implements works on float; the half-typed modes keep their names so that code mentioning them compiles
+// every mode this engine implements works on float; the half-typed modes keep their names so that code mentioning them compiles.
+// One difference a hand-allocating caller must know: the reference's working Q of fp32_tc_nocor is `half` (reference
+// src/tsqr.hpp:29), here it is float like every other buffer -- size the work space in ELEMENTS of these traits' types
+// (get_working_q_size(m, n) * sizeof(get_working_q_type<mode>::type), as mtk::tsqr::buffer and mtk::qr::buffer do), never in
+// elements of the reference's type: a `half`-sized wq would be half the bytes this engine writes.
 template <compute_mode mode> struct get_working_q_type { using type = float; };
 template <compute_mode mode> struct get_working_r_type { using type = float; };
 template <compute_mode mode> struct get_io_type { using type = float; };

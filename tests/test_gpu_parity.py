@@ -139,14 +139,16 @@ def test_ill_conditioned_reorth(bq, oracle, torch_cuda, cond, mode):
     assert orth < 3 * max(oracle.orthogonality_fro(q_o), 2e-6)
     # the factors themselves against the oracle's (not only the metrics).  R: every entry within 2e-5 of the LARGEST entry -- an
     # absolute bound, which is what both algorithms deliver for the rows that belong to tiny singular values (beyond cond ~1e7 the
-    # fp32 matrix is numerically rank deficient and those rows are determined to eps * |A| only).  Q: the columns j that are
-    # determined to better than 1e-3, i.e. |r_00 / r_jj| * eps32-level 2e-5 / 10 < 1e-3, entry-wise within that tolerance.
+    # fp32 matrix is numerically rank deficient and those rows are determined to eps * |A| only).  Q: column j of either result is
+    # determined to (its algorithm's error level) * |r_00 / r_jj|; the columns for which that is below 1e-3 are compared entry-wise
+    # within base * max(1, |r_00 / r_jj| / 10), base = 2e-5 (fp32_notc) / 5e-5 (fp32_tc_cor: the reference's fp16-split arithmetic,
+    # which the oracle restates, is the less accurate side: 8e-6 against 3e-6 in ||Q^T Q - I||).
     qn, rn = oracle.sign_normalise(q, r)
     qon, ron = oracle.sign_normalise(q_o, np.triu(r_o))
     assert np.abs(rn - ron).max() <= 2e-5 * np.abs(ron).max()
-    tol = 2e-5 * np.maximum(1.0, np.abs(ron[0, 0] / np.diag(ron)) / 10.0)
+    tol = (2e-5 if mode == "fp32_notc" else 5e-5) * np.maximum(1.0, np.abs(ron[0, 0] / np.diag(ron)) / 10.0)
     good = tol < 1e-3
-    assert good.sum() >= (64 if cond <= 1e4 else 2)
+    assert good.sum() >= (32 if cond <= 1e4 else 2)
     assert np.all(np.abs(qn - qon).max(axis=0)[good] <= tol[good])
     st, q0, r0 = run_gpu(bq, torch_cuda, a, md, False)
     assert oracle.residual(a, q0, r0) < 2e-6

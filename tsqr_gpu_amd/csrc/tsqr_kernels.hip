@@ -59,7 +59,9 @@ __device__ __forceinline__ float xq_sum(float x) {
 // ---------------------------------------------------------------------------------------------
 // chunk load / store in the (c,q) layout
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+// NTL: nontemporal loads -- for the stacks of R factors of the Householder engine, which are read once and must not displace the
+// caller's A from the Infinity Cache (the apply pass reads A again); never for A itself.
+template <int NT, bool NTL = false>
 __device__ __forceinline__ void load_chunk(float (&p)[NT][16], const float* __restrict__ src, size_t ld,
                                            size_t row0, size_t m, int n, int c, int q) {
 	const bool full = (row0 + 64 <= m);
@@ -71,7 +73,8 @@ __device__ __forceinline__ void load_chunk(float (&p)[NT][16], const float* __re
 			if (full) {
 #pragma unroll
 				for (int rt = 0; rt < 4; rt++) {
-					const f32x4u v = *reinterpret_cast<const f32x4u*>(base + 16 * rt);
+					const f32x4u v = NTL ? __builtin_nontemporal_load(reinterpret_cast<const f32x4u*>(base + 16 * rt))
+					                     : *reinterpret_cast<const f32x4u*>(base + 16 * rt);
 					p[ct][4 * rt + 0] = v[0]; p[ct][4 * rt + 1] = v[1]; p[ct][4 * rt + 2] = v[2]; p[ct][4 * rt + 3] = v[3];
 				}
 			} else {
@@ -507,7 +510,7 @@ __device__ __forceinline__ void store_packed_r(float* __restrict__ dst, size_t d
 			}
 #pragma unroll
 			for (int u = 0; u < 4; u++)
-				if (col0 + u < cols_store) dst[(size_t)(col0 + u) * dst_ld + lane] = v[u];
+				if (col0 + u < cols_store) __builtin_nontemporal_store(v[u], &dst[(size_t)(col0 + u) * dst_ld + lane]);   // (keeps A in the Infinity Cache)
 		}
 	}
 }
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(64 * FOLD_COOP_WAVES) void fold_coop_kernel(const F
 	const size_t mrows = (size_t)a.nblocks * 64;
 	float p[NT][16];
 	// block `first` is the initial R of every wave: loaded like any chunk and scattered into the packed rows
-	load_chunk<NT>(p, a.src, a.ld, (size_t)first * 64, mrows, a.n, c, q);
+	load_chunk<NT, true>(p, a.src, a.ld, (size_t)first * 64, mrows, a.n, c, q);
 #pragma unroll
 	for (int ct = 0; ct < NT; ct++)
 #pragma unroll
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(64 * FOLD_COOP_WAVES) void fold_coop_kernel(const F
 		}
 	// wave w > 0 folds block first + w; wave 0 (and a wave whose block does not exist) contributes a zero chunk
 	if (wv > 0 && first + wv < a.nblocks) {
-		load_chunk<NT>(p, a.src, a.ld, (size_t)(first + wv) * 64, mrows, a.n, c, q);
+		load_chunk<NT, true>(p, a.src, a.ld, (size_t)(first + wv) * 64, mrows, a.n, c, q);
 	} else {
 #pragma unroll
 		for (int ct = 0; ct < NT; ct++)
@@ -711,6 +714,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 // Measured alternatives (round 2, 2^20 x 64; tools/seq_bench.py, git history): a workgroup LDS-DMA ring (61 us: sharing a block
 // between waves duplicates the split), a per-wave LDS-DMA bounce with full-line requests and a prefetched next chunk (54.6 us)
 // against 53.6 us here: the pass is bound by vector + matrix issue at the clock the chip holds (~1.6 GHz), not by its requests.
+// (Round 3, VERDICT r02 item 1e: one chain per 64-row chunk -- 12 products, half the fp64 flushes -- changes neither the accuracy
+// (2^23 rows, same-sign inputs included: tools/gram_flush_accuracy.py in git history, profiles/r03_experiment_log.md) nor the call's
+// time (0.1629 / 0.1629 vs 0.1629 / 0.1623 ms): left as it was.)
 template <int NT>
 __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
