@@ -107,7 +107,7 @@ def test_small_n_ill_conditioned_without_reorth(bq, oracle, torch_cuda, n, cond,
     assert np.abs(np.tril(r, -1)).max() == 0.0
 
 
-@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor", "fp32_tc_nocor"])
 def test_golden_fixtures(bq, oracle, torch_cuda, mode):
     import json, os
     G = os.path.join(os.path.dirname(__file__), "golden")
@@ -117,8 +117,11 @@ def test_golden_fixtures(bq, oracle, torch_cuda, mode):
         st, q, r = run_gpu(bq, torch_cuda, a, bq.compute_mode[mode], False)
         assert st == 0
         absr = np.abs(r)
-        assert np.allclose(absr, data["absr_lapack64"], rtol=0, atol=5e-6 * absr.max())
-        assert np.allclose(absr, data["absr_" + mode], rtol=0, atol=2e-5 * absr.max())
+        assert np.allclose(absr, data["absr_lapack64"], rtol=0, atol=5e-6 * absr.max())     # (R of every mode comes from the corrected Gram path)
+        # the oracle's |R| of the same mode: fp32 modes within 2e-5 of the largest entry; fp32_tc_nocor within the reference
+        # arithmetic's own distance from the exact factor (its fp16 H and products put its R 1e-3 .. 1e-2 away)
+        far = np.abs(data["absr_" + mode] - data["absr_lapack64"]).max()
+        assert np.allclose(absr, data["absr_" + mode], rtol=0, atol=(2e-5 * absr.max() if mode != "fp32_tc_nocor" else far + 5e-6 * absr.max()))
         assert oracle.residual(a, q, r) < case["residual_max"][mode]
         assert oracle.orthogonality_fro(q) < case["orth_fro_max"][mode]
 
