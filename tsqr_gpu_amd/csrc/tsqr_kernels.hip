@@ -518,7 +518,7 @@ __device__ __forceinline__ void store_packed_r(float* __restrict__ dst, size_t d
 // TRI: the folded blocks are 64-row upper-triangular R factors (tree levels with NT == 4): the wave's first block is copied
 // into R instead of folded and every panel skips the row tiles that are structurally zero.
 template <int NT, bool TRI = false, bool COR = false>
-__global__ __launch_bounds__(256, (COR ? 2 : 3)) void fold_kernel(const FoldArgs a) {
+__global__ __launch_bounds__(256, 2) void fold_kernel(const FoldArgs a) {
 	constexpr int NP = 16 * NT;
 	constexpr int RP = (NP * (NP + 1)) / 2 + 16;         // packed upper triangle (+ slack for masked reads)
 	__shared__ float Rs[4][RP];

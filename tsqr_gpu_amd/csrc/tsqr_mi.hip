@@ -131,12 +131,10 @@ struct Plan {
 	size_t stack_b;      // floats needed in wq (levels 1, 3, ... write here)
 };
 
-// occ3: the level-0 kernel runs three waves per SIMD (fold_kernel without the error-corrected block reflectors: 168 VGPRs) -- half as
-// many waves again are resident, so the first level is cut into that many more pieces.  Work-buffer sizes take the larger plan.
-Plan make_plan(size_t m, size_t n, bool occ3 = true) {
+Plan make_plan(size_t m, size_t n) {
 	Plan p{};
 	p.NP = np_of(n);
-	const int level0_waves = g_set.level0_waves.load() * (occ3 ? 3 : 2) / 2, tree_cpw = g_set.tree_cpw.load();
+	const int level0_waves = g_set.level0_waves.load(), tree_cpw = g_set.tree_cpw.load();
 	size_t rows = m;
 	int lv = 0;
 	// a wave turns cpw*64 source rows into NP rows: cpw*64 >= 2*NP keeps every level shrinking
@@ -417,9 +415,9 @@ int fold_coop(Ctx& c, float* r, size_t ldr, float* stack, size_t stack_ld, int n
 // R (n x n, ldr; full block written, zeros below the diagonal) of src (m x n), n <= 64: streaming Householder TSQR + fold tree.
 // stack_a / stack_b: scratch for the R stacks of even / odd levels (Plan::stack_a / stack_b floats).
 int fold_r(Ctx& c, float* r, size_t ldr, const float* src, size_t ld, size_t m, size_t n, float* stack_a, float* stack_b) {
-	const bool cor = c.fold_cor;
-	const Plan p = make_plan(m, n, /*occ3=*/!cor);
+	const Plan p = make_plan(m, n);
 	const int NT = (int)(p.NP / 16);
+	const bool cor = c.fold_cor;
 	const float* cur = src; size_t cur_ld = ld;
 	for (int lv = 0; lv < p.nlevels; lv++) {
 		tsqrmi::FoldArgs a{};
