@@ -119,13 +119,14 @@ int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t 
 
 /* Row-partitioned TSQR (the reference has no multi-GPU path): one call per rank, every rank passes its own
  * row block (m_local may differ between ranks, 1 <= m_local on every rank -- a rank that returns 1 for an empty block would leave
- * the others waiting in their exchange; m_local < n is fine), r is bitwise identical on all ranks on return, n <= 64.  It is the SAME ladder as
+ * the others waiting in their exchange; m_local < n is fine), r is bitwise identical on all ranks on return.  n <= 64 is one panel;
+ * n > 64 runs 64-column panels whose coupling coefficients are all-reduced like the Gram tiles (a is then overwritten).  It is the SAME ladder as
  * tsqr_mi_qr_f32 with two exchange hooks switched on, all enqueued on `stream` with no host wait before the end of the call:
  *   Gram levels:        all-reduce (sum) of the Gram tiles + the local row count: <= 2561 doubles.  Every rank then factors the
  *                       same matrix with thresholds from the same (global) row count, so the accept / reject decisions agree on
  *                       all ranks by construction -- a NaN anywhere reaches everyone through the sum;
  *   Householder engine: all-gather of the n x n local R factors, every rank folds the same (nranks n) x n stack.
- * Work buffers: tsqr_mi_working_{q,r}_size_dist(m_local, n, nranks) elements; gather_buf: nranks*n*n floats.
+ * Work buffers: tsqr_mi_working_{q,r}_size_dist(m_local, n, nranks) elements; gather_buf: nranks * min(n, 64)^2 floats.
  * The communicator and the collectives that run on it must come from ONE RCCL instance (a process may have two mapped: torch
  * bundles a copy, /opt/rocm holds another), so the library never searches for librccl itself:
  * tsqr_mi_qr_f32_dist_fn: the caller passes its ncclComm_t (as void*) together with the addresses of ncclAllReduce and ncclAllGather

@@ -157,6 +157,24 @@ def test_four_ranks_unequal_blocks(oracle, policy):
     _check(res, oracle)
 
 
+@pytest.mark.parametrize("n,policy,reorth", [(100, 0, False), (128, 0, True), (100, 1, False)])
+def test_two_ranks_more_than_64_columns(oracle, n, policy, reorth):
+    """n > 64 over two ranks: 64-column panels, every coupling coefficient block S = Qb^T Ap all-reduced like the Gram tiles (policy 0)
+    or the panel factors all-gathered (policy 1); both ranks end with the same R and a globally orthogonal Q"""
+    import numpy as np
+    heights = (9000, 5001)
+    res = _run(heights, n, reorth=reorth, policy=policy)
+    a, q, r = res["a"], res["q"], res["r"]
+    assert res["st"] == 0 and res["r_same"] and len(set(res["engines"])) == 1
+    assert np.abs(np.tril(r, -1)).max() == 0.0
+    assert np.linalg.norm(q @ r - a) / np.linalg.norm(a) < 5e-7
+    assert np.linalg.norm(q.T @ q - np.eye(n)) < 5e-6
+    q2, r2 = np.linalg.qr(a.astype(np.float64))
+    _, rn = oracle.sign_normalise(q, r)
+    _, r2n = oracle.sign_normalise(q2, r2)
+    assert np.abs(rn - r2n).max() / np.abs(r2n).max() < 1e-5
+
+
 def test_two_ranks_ill_conditioned_escalates_identically(oracle):
     """cond 1e9 (1e7..1e8 after rounding to fp32): the bf16 and fp64 Gram levels reject on both ranks (same all-reduced matrix, same
     thresholds), the shifted Cholesky QR two-step finishes the first sweep, the reorthogonalisation sweep brings Q back to O(eps)"""

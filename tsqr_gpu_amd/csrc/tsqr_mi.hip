@@ -1006,10 +1006,12 @@ size_t working_r_need(size_t m, size_t n) {
 
 int qr_dist_common(Ctx& c, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m_local, size_t n,
                    void* wq, void* wr, int nranks, void* stream) {
-	if (m_local == 0 || n == 0 || n > PW || nranks < 1) return TSQR_MI_ERROR_INVALID_SIZE;
+	// (n > 64: 64-column panels coupled by block Gram-Schmidt, every coupling coefficient block all-reduced like the Gram tiles; the
+	// one-panel path for 64 < n <= 128 is a single-GPU path)
+	if (m_local == 0 || n == 0 || nranks < 1) return TSQR_MI_ERROR_INVALID_SIZE;
 	const int engine = engine_of(mode);
 	if (engine < 0) { t_last_error = "compute_mode not implemented on gfx950"; return TSQR_MI_ERROR_UNSUPPORTED; }
-	init_ctx(c, wq, wr, std::max(m_local, (size_t)nranks * n), n, stream);
+	init_ctx(c, wq, wr, std::max(m_local, (size_t)nranks * std::min(n, PW)), n, stream);
 	c.comm.nranks = nranks;
 	c.rows_global = (double)m_local * (double)nranks;    // host-side estimate only: the device thresholds use the all-reduced count
 	resolve_host_sig(c, nullptr, m_local);
@@ -1040,12 +1042,13 @@ size_t tsqr_mi_working_reorth_size(size_t m) { return 16 * 16 * 2 + m * 16; }
 // row-partitioned call: the work buffers must also hold the restacked (nranks n) x n matrix of gathered R factors and its fold
 size_t tsqr_mi_working_q_size_dist(size_t m_local, size_t n, int nranks) {
 	if (m_local == 0 || n == 0 || nranks < 1) return 0;
-	return tsqr_mi_working_q_size(std::max(m_local, (size_t)nranks * n), n);
+	return tsqr_mi_working_q_size(std::max(m_local, (size_t)nranks * std::min(n, PW)), n);
 }
 size_t tsqr_mi_working_r_size_dist(size_t m_local, size_t n, int nranks) {
 	if (m_local == 0 || n == 0 || nranks < 1) return 0;
-	const size_t stack = (((size_t)nranks * n * n + 63) & ~(size_t)63) + make_plan((size_t)nranks * n, n).stack_a;
-	return std::max(tsqr_mi_working_r_size(std::max(m_local, (size_t)nranks * n), n), std::max(working_r_need(m_local, n), stack));
+	const size_t pc = std::min(n, PW);                   // (the gathered stack is one panel's: nranks * pc rows of pc columns)
+	const size_t stack = (((size_t)nranks * pc * pc + 63) & ~(size_t)63) + make_plan((size_t)nranks * pc, pc).stack_a;
+	return std::max(tsqr_mi_working_r_size(std::max(m_local, (size_t)nranks * pc), n), std::max(working_r_need(m_local, n), stack));
 }
 
 void tsqr_mi_profile_enable(int on) {

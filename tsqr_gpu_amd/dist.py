@@ -134,13 +134,13 @@ class HipBackend:
     """The product: one C-ABI call per factorisation (libtsqr_mi.so; raises if the library is missing -- no CPU fallback)."""
 
     def __init__(self, mode, m_local, n, world, comm=None, collectives=None):
-        assert n <= 64, "the row-partitioned path factors one 64-wide panel"
         self.mode = bq.compute_mode(mode)
         self.n, self.m_local, self.world = n, m_local, world
         L = bq.lib()
         self.wq = torch.empty(max(L.tsqr_mi_working_q_size_dist(m_local, n, world), 1), dtype=torch.float32, device="cuda")
         self.wr = torch.empty(max(L.tsqr_mi_working_r_size_dist(m_local, n, world), 1), dtype=torch.float32, device="cuda")
-        self.gather = torch.empty(world * n * n, dtype=torch.float32, device="cuda")
+        pc = min(n, 64)                                # (n > 64: 64-column panels; the all-gather is one panel's factors)
+        self.gather = torch.empty(world * pc * pc, dtype=torch.float32, device="cuda")
         self.comm = comm                               # RcclComm or None
         self.coll = collectives or TorchCollectives()
         self._cb_error = None
