@@ -175,6 +175,26 @@ def test_error_codes_on_gpu(bq, torch_cuda):
         bf.allocate(8, 4)                                            # reference src/blockqr.hpp:77-79
 
 
+def test_call_loop_entry_point(bq, oracle, torch_cuda):
+    """tsqr_mi_qr_f32_loop (the reference's speed loop, src/test.cu:299-309, on the C side of the ABI): count back-to-back blocking
+    calls give bit for bit what one call gives, the first non-zero state is returned, count = 0 does nothing."""
+    torch = torch_cuda
+    m, n = 20000, 64
+    a = oracle.uniform_matrix(m, n, seed=3)
+    d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    bf = bq.buffer(bq.compute_mode.fp32_tc_cor, False); bf.allocate(m, n)
+    q1 = torch.empty(n, m, device="cuda"); r1 = torch.zeros(n, n, device="cuda")
+    assert bq.qr(q1, m, r1, n, d_a, m, m, n, bf) == 0
+    q3 = torch.full((n, m), float("nan"), device="cuda"); r3 = torch.zeros(n, n, device="cuda")
+    loop = bq.bind_loop(q3, m, r3, n, d_a, m, m, n, bf)
+    assert loop(0) == 0 and bool(torch.isnan(q3).all())
+    assert loop(3) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q3) and torch.equal(r1, r3)
+    bad = bq.bind_loop(q3, 4, r3, 8, d_a, 4, 4, 8, bf)                  # n > m: every call of the loop returns 1, the loop stops at once
+    assert bad(5) == bq.error_invalid_matrix_size
+
+
 def test_input_not_clobbered_for_single_panel(bq, oracle, torch_cuda):
     torch = torch_cuda
     m, n = 3000, 64
