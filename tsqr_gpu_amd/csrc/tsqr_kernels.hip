@@ -885,7 +885,8 @@ __shared__ unsigned long long chol_stamp_lds[4 * CHOL_NSTAMP];
 // waves apply the four rank-1 updates to their remaining rows.  16 barriers for 64 rows; after the four groups of a block
 // the register rows rotate by four so the active block is always slots 0..3.
 template <int U>
-__device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* Rf, float* Zf, double* Zd,
+__device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* __restrict__ r, size_t ldr,
+                                           float* __restrict__ z, int NP, double* Zd,
                                            double* pv, int w, int j, int n, int kk, double dgj, double& s_acc) {
 	const int K0 = 16 * kk + 4 * U;
 	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
@@ -918,7 +919,7 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 		});
 	}
 	CHOL_STAMP(8 + 8 * (4 * kk + U) + 1);
-	__syncthreads();
+	lds_barrier();                                       // (LDS only: the result stores below stay in flight across the groups)
 	CHOL_STAMP(8 + 8 * (4 * kk + U) + 2);
 	double rkj[4], mkc[4];
 #pragma unroll
@@ -928,8 +929,11 @@ __device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], do
 		for (int u = 0; u < 4; u++) {
 			const int K = K0 + u;
 			if (K < n) {
-				Rf[K * 65 + j] = (float)rkj[u];
-				Zf[K * 65 + j] = (j <= K) ? (float)mkc[u] : 0.0f;                    // Z[j][K] = M[K][j]
+				// the finished rows leave for global memory at once (round 3: the stores overlap the rest of the elimination instead
+				// of forming a 5 K-cycle tail): column K of Z = row K of M, contiguous; row K of R, strided by ldr, exact zeros
+				// below the diagonal
+				if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mkc[u] : 0.0f;     // Z[j][K] = M[K][j]
+				if (j < n) r[(size_t)j * ldr + K] = (j >= K) ? (float)rkj[u] : 0.0f;
 				Zd[K * 65 + j] = (j <= K) ? mkc[u] : 0.0;                            // (fp64 image, read on by chol_wide_kernel)
 				if (j <= K) s_acc = fma(dgj * mkc[u], mkc[u], s_acc);                // sum of g_jj * Z[j][K]^2
 			}
@@ -961,9 +965,6 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
                                           float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double** gs_out = nullptr) {
 	__shared__ double Gs[64 * 65];               // symmetric G (assembly); afterwards the fp64 image of Z: Gs[K * 65 + j] = Z[j][K]
 	if (gs_out) *gs_out = Gs;                    // (a caller in the same kernel may go on with that image: chol_wide_kernel)
-	__shared__ float Rf[64 * 65];                // R rows for the final store
-	__shared__ float Zf[64 * 65];                // rows of M = columns of Z for the final store (no global store inside the loop:
-	                                             // a workgroup barrier drains vmcnt, i.e. would wait for the store's round trip)
 	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
 	const int t = threadIdx.x;
 	const int j = t & 63, w = t >> 6;
@@ -983,7 +984,7 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 			}
 	}
 	if (NT < 4)                                          // with all ten tiles present every entry of Gs is written below
-		for (int i = t; i < 64 * 65; i += 256) Gs[i] = 0.0;  // (Rf needs no initialisation: rows K < n are written in full)
+		for (int i = t; i < 64 * 65; i += 256) Gs[i] = 0.0;
 	for (int e = n * NP + t; e < NP * NP; e += 256) z[e] = 0.0f;          // padding rows of Z
 	__syncthreads();
 	{
@@ -1032,7 +1033,7 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 	CHOL_STAMP(1);
 #pragma unroll 1
 	for (int kk = 0; kk < 4; kk++) {
-		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, Rf, Zf, Gs, pv, w, j, n, kk, dgj, s_acc); });
+		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, r, ldr, z, NP, Gs, pv, w, j, n, kk, dgj, s_acc); });
 #pragma unroll
 		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
 	}
@@ -1070,25 +1071,7 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 			}
 		}
 	}
-	// Z out (fp32: column K of Z = row K of M; the padding rows were zeroed at the start) and R out (fp32, exact zeros below the
-	// diagonal) from their LDS images, coalesced
-	{
-		// (fixed trip counts: every LDS read of the two images is issued before the first store needs its value)
-		float zv[16], rv[16];
-		const int i = t & 63;
-#pragma unroll
-		for (int u = 0; u < 16; u++) {
-			const int K = w + 4 * u;
-			zv[u] = Zf[min(K, 63) * 65 + j];
-			rv[u] = Rf[i * 65 + min(K, 63)];
-		}
-#pragma unroll
-		for (int u = 0; u < 16; u++) {
-			const int K = w + 4 * u;
-			if (K < n && j < NP) z[(size_t)K * NP + j] = zv[u];
-			if (K < n && i < n) r[(size_t)K * ldr + i] = (i <= K) ? rv[u] : 0.0f;
-		}
-	}
+	// (R and Z have left for global memory row by row during the elimination: chol_group)
 	CHOL_STAMP(3);
 #ifdef TSQR_CHOL_STAMPS
 	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 4] = __builtin_amdgcn_s_memrealtime();
@@ -1335,7 +1318,7 @@ struct ApplyArgs {
 
 // ---------------------------------------------------------------------------------------------
 // apply_wg_kernel: the product Q = A * Z organised per WORKGROUP for the DRAM access pattern.
-// Measured (tools/pattern_bench*.py, 2^20 x 64, lda = 2^20): a wave that touches 64 columns x 256 B per chunk copies at
+// Measured (round 1, tools/pattern_bench*.py in git history, 2^20 x 64, lda = 2^20): a wave that touches 64 columns x 256 B per chunk copies at
 // 4.4 TB/s, a workgroup that moves ROWS*4 contiguous bytes of ONE column per instruction (loads and stores) at 5.0-5.2 TB/s,
 // independent of the power-of-two column stride.  So:
 //   * a workgroup owns ROWS x NP blocks (interleaved over the grid); wave w loads columns {(w+4k)*CPI + ...}, each load
