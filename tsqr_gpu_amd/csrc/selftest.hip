@@ -66,7 +66,13 @@ extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* st
 	a.rows = rows; a.shift_coef = (level == 3) ? 11.0 * 1.1102230246251565e-16 : 0.0; a.n = n; a.NT = NT; a.level = level; a.scond_floor = 4.0f;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	auto launch = [&]() { hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a); };
+	// reps >= 1000: the sixteen-wave form (chol16_kernel) with reps % 1000 timed launches
+	const bool w16 = reps >= 1000;
+	reps %= 1000;
+	auto launch = [&]() {
+		if (w16) hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, 0, a);
+		else hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a);
+	};
 	launch();
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++) launch();
@@ -82,14 +88,17 @@ extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* st
 
 // ---- in-kernel time stamps of chol_kernel (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----
 extern "C" int tsqr_selftest_chol_stamps(unsigned long long* out_dev, float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT,
-                                         int level, double rows) {
+                                         int level, double rows, int w16) {
 #ifdef TSQR_CHOL_STAMPS
 	tsqrmi::CholArgs a{};
 	a.r = r; a.ldr = ldr; a.z = z; a.status = status; a.host_status = nullptr; a.gsum = gsum; a.prev_status = nullptr; a.rows_dev = nullptr;
 	a.rows = rows; a.shift_coef = 0.0; a.n = n; a.NT = NT; a.level = level; a.scond_floor = 4.0f;
 	unsigned long long* null_out = nullptr;
 	hipMemcpyToSymbol(HIP_SYMBOL(tsqrmi::g_chol_stamp_out), &null_out, sizeof(null_out));
-	auto launch = [&]() { hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a); };
+	auto launch = [&]() {
+		if (w16) hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, 0, a);
+		else hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a);
+	};
 	for (int i = 0; i < 20; i++) launch();               // warm: clocks, instruction cache
 	hipMemcpyToSymbol(HIP_SYMBOL(tsqrmi::g_chol_stamp_out), &out_dev, sizeof(out_dev));
 	launch();

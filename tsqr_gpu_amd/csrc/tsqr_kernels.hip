@@ -875,9 +875,12 @@ __device__ unsigned long long* g_chol_stamp_out = nullptr;           // [4 waves
 constexpr int CHOL_NSTAMP = 160;
 __shared__ unsigned long long chol_stamp_lds[4 * CHOL_NSTAMP];
 #define CHOL_STAMP(slot) do { if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CHOL_STAMP16(slot) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CHOL_STAMP(slot) do {} while (0)
+#define CHOL_STAMP16(slot) do {} while (0)
 #endif
+typedef double f64x2c __attribute__((ext_vector_type(2)));
 
 // Row ownership of the elimination kernels: thread (w, j) holds column j of the rows  row(w, s) = 16*(s>>2) + 4*w + (s&3),
 // i.e. every wave owns FOUR consecutive rows of each 16-row block.  A "group" = those four rows: its owner factors them
@@ -1081,6 +1084,187 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// chol_body16 (round 3): the same step on SIXTEEN waves -- wave w owns the four rows 4w .. 4w+3 of G and of M = R^-T, i.e. exactly
+// one group of four pivots.  Why: in-kernel stamps of chol_body (tools/chol_stamps.py) show that a group costs the owner's section
+// (~1.25 K cycles) PLUS the rank-4 update of every wave's 16 rows (128 fp64 FMAs = ~1.4 K cycles, one v_fma_f64 per ~10 cycles and
+// wave) before the next owner can start.  With one group per wave the update between two owner sections is four rows (32 FMAs),
+// no rows rotate, and the sixteen waves (four per SIMD) share the fp64 pipes for the updates.  Same arithmetic per entry, same
+// status words, same interface as chol_body minus the fp64 image of Z (only chol_wide_kernel needs that).
+// ---------------------------------------------------------------------------------------------
+template <class LOADG>
+__device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
+                                            unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
+                                            float max_scond, double shift_coef = 0.0, double min_diag = 0.0) {
+	__shared__ double Gs[64 * 65];               // symmetric G (assembly)
+	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64], sred[16];
+	const int t = threadIdx.x;
+	const int j = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int NP = 16 * NT;
+	CHOL_STAMP16(0);
+#ifdef TSQR_CHOL_STAMPS
+	if ((threadIdx.x & 63) == 0 && w < 4) chol_stamp_lds[w * CHOL_NSTAMP + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+	// the first four waves assemble G exactly as chol_body does (one value per thread and tile); the others wait at the barriers
+	double gv[10];
+	if (t < 256) {
+		int idx = 0;
+		for (int ti = 0; ti < 4; ti++)
+			for (int tj = ti; tj < 4; tj++) {
+				if (ti < NT && tj < NT) { gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = loadg(idx * 256 + t); idx++; }
+				else gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = 0.0;
+			}
+	}
+	if (NT < 4)
+		for (int i = t; i < 64 * 65; i += 1024) Gs[i] = 0.0;
+	for (int e = n * NP + t; e < NP * NP; e += 1024) z[e] = 0.0f;         // padding rows of Z
+	__syncthreads();
+	if (t < 256) {
+		const int reg = t >> 6, l = t & 63;
+#pragma unroll
+		for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+			for (int tj = ti; tj < 4; tj++) {
+				if (ti < NT && tj < NT) {
+					const int row = 16 * ti + (f32_layout ? 4 * (l >> 4) + reg : (l >> 4) + 4 * reg);
+					const int col = 16 * tj + (l & 15);
+					const double v = gv[ti * 4 + tj - (ti * (ti + 1)) / 2];
+					if (row <= col) {                    // (upper-triangle owner writes both mirror positions: see chol_body)
+						Gs[row * 65 + col] = v;
+						Gs[col * 65 + row] = v;
+					}
+				}
+			}
+	}
+	__syncthreads();
+	if (shift_coef > 0.0) {                              // shifted Cholesky: G + s I, s = shift_coef * trace(G)
+		if (w == 0) {
+			double tr = (j < n) ? Gs[j * 65 + j] : 0.0;
+			for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+			if (j < n) Gs[j * 65 + j] += shift_coef * tr;
+		}
+		__syncthreads();
+	}
+	double g[4], mm[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const int i = 4 * w + u;
+		g[u] = Gs[i * 65 + j];
+		mm[u] = (i == j) ? 1.0 : 0.0;
+	}
+	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; }
+	const double dgj = Gs[j * 65 + j];
+	double s_acc = 0.0;
+	__syncthreads();
+	CHOL_STAMP16(1);
+	const int ngroups = (n + 3) >> 2;
+#pragma unroll 1
+	for (int gi = 0; gi < ngroups; gi++) {
+		const int K0 = 4 * gi;
+		double* rr = Rrow + (gi & 1) * 256;              // [4][64]
+		double* mr = Mrow + (gi & 1) * 256;
+		CHOL_STAMP16(8 + 8 * gi + 0);
+		if (w == gi) {
+			// owner: the four pivots of the group, rows factored against each other in registers (lane broadcasts)
+			static_for<0, 4>([&](auto uu) {
+				constexpr int u = decltype(uu)::value;
+				const int K = K0 + u;
+				const double piv0 = bcast_lane_f64(g[u], K);
+				const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
+				double y = __builtin_amdgcn_rsq(piv);
+				y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);      // one Newton step
+				const bool live = K < n;
+				const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
+				const double mk = live ? mm[u] * y : 0.0;
+				static_for<u + 1, 4>([&](auto vv) {
+					constexpr int v = decltype(vv)::value;
+					const double rkv = bcast_lane_f64(rk, K0 + v);   // R[K][K0+v]
+					g[v] = fma(-rkv, rk, g[v]);
+					mm[v] = fma(-rkv, mk, mm[v]);
+				});
+				rr[u * 64 + j] = rk;
+				mr[u * 64 + j] = mk;
+				if (j == 0 && live) pv[K] = piv0;
+			});
+		}
+		CHOL_STAMP16(8 + 8 * gi + 1);
+		lds_barrier();                                   // (LDS only: the result stores below stay in flight)
+		CHOL_STAMP16(8 + 8 * gi + 2);
+		if (w > gi) {
+			// the four rows of this wave: R part first (the next owner's pivots wait for it), then M
+			double rki[4][4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const f64x2c a01 = *reinterpret_cast<const f64x2c*>(&rr[u * 64 + 4 * w]);
+				const f64x2c a23 = *reinterpret_cast<const f64x2c*>(&rr[u * 64 + 4 * w + 2]);
+				rki[u][0] = a01[0]; rki[u][1] = a01[1]; rki[u][2] = a23[0]; rki[u][3] = a23[1];      // R[K0+u][4w .. 4w+3]
+			}
+			double rkj[4], mkc[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) rkj[u] = rr[u * 64 + j];
+#pragma unroll
+			for (int u = 0; u < 4; u++) mkc[u] = mr[u * 64 + j];
+#pragma unroll
+			for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+				for (int u = 0; u < 4; u++) g[sl] = fma(-rki[u][sl], rkj[u], g[sl]);
+#pragma unroll
+			for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+				for (int u = 0; u < 4; u++) mm[sl] = fma(-rki[u][sl], mkc[u], mm[sl]);
+		}
+		if (w == ((gi + 15) & 15)) {
+			// a wave that is off the path (the previous owner: its rows are finished; for the first group the last wave, which is
+			// fifteen groups away from owning): the finished rows leave for global memory, the verdict sum grows
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int K = K0 + u;
+				const double rkj = rr[u * 64 + j], mkc = mr[u * 64 + j];
+				if (K < n) {
+					if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mkc : 0.0f;     // Z[j][K] = M[K][j]
+					if (j < n) r[(size_t)j * ldr + K] = (j >= K) ? (float)rkj : 0.0f;
+					if (j <= K) s_acc = fma(dgj * mkc, mkc, s_acc);                        // sum of g_jj * Z[j][K]^2
+				}
+			}
+		}
+		CHOL_STAMP16(8 + 8 * gi + 3);
+	}
+	CHOL_STAMP16(2);
+	// scaled conditioning S and the status words, as in chol_body
+	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
+	if (j == 0) sred[w] = s_acc;
+	__syncthreads();
+	if (w == 0) {
+		const double d0 = dg[j], p0 = pv[j];
+		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
+		if (j < n && !(d0 >= min_diag)) ratio = 0.0f;
+		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
+		if (j == 0) {
+			double ssum = 0.0;
+#pragma unroll
+			for (int k = 0; k < 16; k++) ssum += sred[k];
+			const float scond = (float)(ssum / (double)n);
+			const unsigned s0 = (ratio > min_ratio && scond <= max_scond) ? 0u : 1u;     // NaN compares false -> rejected
+			status[0] = s0;
+			status[1] = __builtin_bit_cast(unsigned, ratio);
+			status[2] = __builtin_bit_cast(unsigned, scond);
+			if (host_status) {
+				volatile unsigned* hs = host_status;
+				hs[1] = __builtin_bit_cast(unsigned, ratio);
+				hs[2] = __builtin_bit_cast(unsigned, scond);
+				hs[0] = s0;
+			}
+		}
+	}
+	CHOL_STAMP16(3);
+#ifdef TSQR_CHOL_STAMPS
+	if ((threadIdx.x & 63) == 0 && w < 4) chol_stamp_lds[w * CHOL_NSTAMP + 4] = __builtin_amdgcn_s_memrealtime();
+	__syncthreads();
+	if (g_chol_stamp_out)
+		for (int i = threadIdx.x; i < 4 * CHOL_NSTAMP; i += 1024) g_chol_stamp_out[i] = chol_stamp_lds[i];
+#endif
+}
+
 struct CholArgs {
 	float* r; size_t ldr;                // R out: n x n, full block written (zeros below the diagonal)
 	float* z;                            // Z = inverse(R) out: NP x NP column-major (ld NP), zero padded
@@ -1122,6 +1306,31 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
 	}
 	chol_body(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
 	          shift, min_diag);
+}
+
+// the 64-column path's launch: sixteen waves (chol_body16)
+__global__ __launch_bounds__(1024) void chol16_kernel(const CholArgs a) {
+	if (a.prev_status && a.prev_status[0] != 0) {
+		if (threadIdx.x == 0) {
+			a.status[0] = 1u; a.status[1] = 0u; a.status[2] = 0u;
+			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
+		}
+		return;
+	}
+	const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
+	float min_ratio = 0.0f, max_scond = INFINITY;
+	double min_diag = 0.0, shift = 0.0;
+	if (a.level == 2) {
+		min_ratio = 0.03125f;
+		max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
+		min_diag = rows * 0x1p-90;
+	} else if (a.level == 1) {
+		min_ratio = 9.094947017729282e-13f;              // 2^-40
+	} else {
+		shift = a.shift_coef * (rows * (double)a.n + (double)a.n * (double)(a.n + 1));
+	}
+	chol_body16(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
+	            shift, min_diag);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -50,6 +50,7 @@ struct Settings {
 	// conditioning S, and a diagnostic print of every Cholesky verdict
 	const float bf16_scond_floor = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);
 	const int debug = env_int("TSQR_MI_DEBUG", 0);
+	const int chol16 = env_int("TSQR_MI_CHOL16", 1);             // (A/B of the round: the Cholesky step on sixteen waves)
 };
 Settings g_set;
 std::atomic<unsigned> g_seq{0};                        // sequence numbers of the completion flags (any thread)
@@ -504,7 +505,8 @@ int chol_from_g(Ctx& c, float* r, size_t ldr, size_t n, int level) {
 	a.n = (int)n; a.NT = NT; a.level = level; a.scond_floor = g_set.bf16_scond_floor;
 	{
 		ProfScope ps(KC_CHOL, c.st);
-		hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, a);
+		if (g_set.chol16) hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, a);
+		else hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, a);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
