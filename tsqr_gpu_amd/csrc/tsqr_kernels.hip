@@ -1158,64 +1158,74 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 	__syncthreads();
 	CHOL_STAMP16(1);
 	const int ngroups = (n + 3) >> 2;
-#pragma unroll 1
-	for (int gi = 0; gi < ngroups; gi++) {
+	// owner section of group gi: the four pivots, rows factored against each other in registers (lane broadcasts), published
+	auto section = [&](int gi) {
 		const int K0 = 4 * gi;
 		double* rr = Rrow + (gi & 1) * 256;              // [4][64]
 		double* mr = Mrow + (gi & 1) * 256;
-		CHOL_STAMP16(8 + 8 * gi + 0);
-		if (w == gi) {
-			// owner: the four pivots of the group, rows factored against each other in registers (lane broadcasts)
-			static_for<0, 4>([&](auto uu) {
-				constexpr int u = decltype(uu)::value;
-				const int K = K0 + u;
-				const double piv0 = bcast_lane_f64(g[u], K);
-				const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
-				double y = __builtin_amdgcn_rsq(piv);
-				y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);      // one Newton step
-				const bool live = K < n;
-				const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
-				const double mk = live ? mm[u] * y : 0.0;
-				static_for<u + 1, 4>([&](auto vv) {
-					constexpr int v = decltype(vv)::value;
-					const double rkv = bcast_lane_f64(rk, K0 + v);   // R[K][K0+v]
-					g[v] = fma(-rkv, rk, g[v]);
-					mm[v] = fma(-rkv, mk, mm[v]);
-				});
-				rr[u * 64 + j] = rk;
-				mr[u * 64 + j] = mk;
-				if (j == 0 && live) pv[K] = piv0;
+		static_for<0, 4>([&](auto uu) {
+			constexpr int u = decltype(uu)::value;
+			const int K = K0 + u;
+			const double piv0 = bcast_lane_f64(g[u], K);
+			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
+			double y = __builtin_amdgcn_rsq(piv);
+			y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);      // one Newton step
+			const bool live = K < n;
+			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
+			const double mk = live ? mm[u] * y : 0.0;
+			static_for<u + 1, 4>([&](auto vv) {
+				constexpr int v = decltype(vv)::value;
+				const double rkv = bcast_lane_f64(rk, K0 + v);   // R[K][K0+v]
+				g[v] = fma(-rkv, rk, g[v]);
+				mm[v] = fma(-rkv, mk, mm[v]);
 			});
+			rr[u * 64 + j] = rk;
+			mr[u * 64 + j] = mk;
+			if (j == 0 && live) pv[K] = piv0;
+		});
+	};
+	// rank-4 update of this wave's four rows with the published rows of group gi: R part first (an owner's pivots wait for it), then M
+	auto update = [&](int gi) {
+		const double* rr = Rrow + (gi & 1) * 256;
+		const double* mr = Mrow + (gi & 1) * 256;
+		double rki[4][4], rkj[4], mkc[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const f64x2c a01 = *reinterpret_cast<const f64x2c*>(&rr[u * 64 + 4 * w]);
+			const f64x2c a23 = *reinterpret_cast<const f64x2c*>(&rr[u * 64 + 4 * w + 2]);
+			rki[u][0] = a01[0]; rki[u][1] = a01[1]; rki[u][2] = a23[0]; rki[u][3] = a23[1];      // R[K0+u][4w .. 4w+3]
+			rkj[u] = rr[u * 64 + j];
+			mkc[u] = mr[u * 64 + j];
 		}
+#pragma unroll
+		for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+			for (int u = 0; u < 4; u++) g[sl] = fma(-rki[u][sl], rkj[u], g[sl]);
+#pragma unroll
+		for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+			for (int u = 0; u < 4; u++) mm[sl] = fma(-rki[u][sl], mkc[u], mm[sl]);
+	};
+	if (w == 0) section(0);
+#pragma unroll 1
+	for (int gi = 0; gi < ngroups; gi++) {
 		CHOL_STAMP16(8 + 8 * gi + 1);
-		lds_barrier();                                   // (LDS only: the result stores below stay in flight)
+		lds_barrier();                                   // group gi's rows are published (LDS only: result stores stay in flight)
 		CHOL_STAMP16(8 + 8 * gi + 2);
-		if (w > gi) {
-			// the four rows of this wave: R part first (the next owner's pivots wait for it), then M
-			double rki[4][4];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const f64x2c a01 = *reinterpret_cast<const f64x2c*>(&rr[u * 64 + 4 * w]);
-				const f64x2c a23 = *reinterpret_cast<const f64x2c*>(&rr[u * 64 + 4 * w + 2]);
-				rki[u][0] = a01[0]; rki[u][1] = a01[1]; rki[u][2] = a23[0]; rki[u][3] = a23[1];      // R[K0+u][4w .. 4w+3]
-			}
-			double rkj[4], mkc[4];
-#pragma unroll
-			for (int u = 0; u < 4; u++) rkj[u] = rr[u * 64 + j];
-#pragma unroll
-			for (int u = 0; u < 4; u++) mkc[u] = mr[u * 64 + j];
-#pragma unroll
-			for (int sl = 0; sl < 4; sl++)
-#pragma unroll
-				for (int u = 0; u < 4; u++) g[sl] = fma(-rki[u][sl], rkj[u], g[sl]);
-#pragma unroll
-			for (int sl = 0; sl < 4; sl++)
-#pragma unroll
-				for (int u = 0; u < 4; u++) mm[sl] = fma(-rki[u][sl], mkc[u], mm[sl]);
+		if (w == gi + 1 && gi + 1 < ngroups) {
+			// the next owner: update and owner section as ONE block of straight-line code -- the update of its rows of M has no
+			// part in the pivot chain and fills the chain's latency gaps instead of standing in front of it
+			update(gi);
+			section(gi + 1);
+		} else if (w > gi) {
+			update(gi);
 		}
 		if (w == ((gi + 15) & 15)) {
 			// a wave that is off the path (the previous owner: its rows are finished; for the first group the last wave, which is
 			// fifteen groups away from owning): the finished rows leave for global memory, the verdict sum grows
+			const int K0 = 4 * gi;
+			const double* rr = Rrow + (gi & 1) * 256;
+			const double* mr = Mrow + (gi & 1) * 256;
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
 				const int K = K0 + u;
