@@ -1090,13 +1090,14 @@ __device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, flo
 // (~1.25 K cycles) PLUS the rank-4 update of every wave's 16 rows (128 fp64 FMAs = ~1.4 K cycles, one v_fma_f64 per ~10 cycles and
 // wave) before the next owner can start.  With one group per wave the update between two owner sections is four rows (32 FMAs),
 // no rows rotate, and the sixteen waves (four per SIMD) share the fp64 pipes for the updates.  Same arithmetic per entry, same
-// status words, same interface as chol_body minus the fp64 image of Z (only chol_wide_kernel needs that).
+// status words, same interface as chol_body.
 // ---------------------------------------------------------------------------------------------
 template <class LOADG>
 __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
                                             unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
-                                            float max_scond, double shift_coef = 0.0, double min_diag = 0.0) {
-	__shared__ double Gs[64 * 65];               // symmetric G (assembly)
+                                            float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double** gs_out = nullptr) {
+	__shared__ double Gs[64 * 65];               // symmetric G (assembly); afterwards the fp64 image of Z: Gs[K * 65 + j] = Z[j][K]
+	if (gs_out) *gs_out = Gs;                    // (a caller in the same kernel may go on with that image: chol_wide_kernel)
 	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64], sred[16];
 	const int t = threadIdx.x;
 	const int j = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1233,6 +1234,7 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 				if (K < n) {
 					if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mkc : 0.0f;     // Z[j][K] = M[K][j]
 					if (j < n) r[(size_t)j * ldr + K] = (j >= K) ? (float)rkj : 0.0f;
+					Gs[K * 65 + j] = (j <= K) ? mkc : 0.0;                                 // (fp64 image, read on by chol_wide_kernel)
 					if (j <= K) s_acc = fma(dgj * mkc, mkc, s_acc);                        // sum of g_jj * Z[j][K]^2
 				}
 			}

@@ -820,7 +820,7 @@ int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, c
 		wa.host_status = c.hsig.dev ? c.hsig.dev + 4 * c.slot : nullptr;
 		wa.prev_status = c.prev_slot >= 0 ? c.status_dev(c.prev_slot) : nullptr;
 		wa.rows = (double)m; wa.scond_floor = g_set.bf16_scond_floor;
-		hipLaunchKernelGGL(tsqrmi::chol_wide_kernel, dim3(1), dim3(256), 0, c.st, wa);
+		hipLaunchKernelGGL(tsqrmi::chol_wide_kernel, dim3(1), dim3(1024), 0, c.st, wa);
 	}
 	HIPCHK(hipGetLastError());
 	tsqrmi::ApplyArgs aa{};

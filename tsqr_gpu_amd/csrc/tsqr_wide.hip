@@ -6,8 +6,8 @@
 // with ONE read of A for G and one read + one write for Q (1.6 GB):
 //   gram_wide_kernel   : all 36 Gram tiles of a 64-row x 128-column block; the block is split ONCE into its three bf16 images in LDS
 //                        and every wave takes nine tile pairs (tile rows w and 7-w) with both MFMA operands read from LDS
-//   chol_wide_kernel   : one workgroup, one launch: chol(G11) -> R11, Z11 [chol_body]; R12 = Z11^T G12, G22' = G22 - R12^T R12;
-//                        chol(G22') -> R22, Z22 [chol_body]; Z12 = -Z11 R12 Z22, the 128 x 128 Z for the apply pass, the verdict
+//   chol_wide_kernel   : one workgroup of sixteen waves, one launch: chol(G11) -> R11, Z11 [chol_body16]; R12 = Z11^T G12, G22' = G22 - R12^T R12;
+//                        chol(G22') -> R22, Z22 [chol_body16]; Z12 = -Z11 R12 Z22, the 128 x 128 Z for the apply pass, the verdict
 //                        over BOTH blocks (scaled conditioning S with the ORIGINAL diagonal of G, pivot ratios)
 //   apply_wide_kernel  : Q = A * Z  (tsqr_kernels.hip)
 // The acceptance rule is the bf16-split Gram level's; a rejected factorisation leaves A untouched and the
@@ -253,138 +253,96 @@ struct CholWideArgs {
 	const unsigned* prev_status;
 	const double* rows_dev; double rows; float scond_floor;
 };
-__global__ __launch_bounds__(256) void chol_wide_kernel(const CholWideArgs a) {
+// Round 3: sixteen waves.  The two 64 x 64 factorisations are chol_body16 (one group of four pivots per wave); the four 64^3 fp64
+// products run on the fp64 matrix cores: wave w owns the 16 x 16 output tile (w >> 2, w & 3) and chains v_mfma_f64_16x16x4_f64 over
+// the inner index, both operands one ds_read_b64 per lane straight from the LDS images (a 2 x 2 register-block VALU form of the
+// same products is LDS-bandwidth-bound: 4 reads per 4 FMAs, ~6.8 us per full product on sixteen waves).  G22' goes to the second
+// factorisation through LDS in the fp64 accumulator layout the matrix cores leave it in.  67.5 -> 56 (VALU products) -> us.
+template <class FA, class FB>
+__device__ __forceinline__ f64x4 tile_product_f64(FA fa, FB fb, int ks0, int ks1, int lq) {
+	f64x4 c = f64x4{0.0, 0.0, 0.0, 0.0};                // c[reg] = C[lq + 4 reg][lane & 15]
+#pragma unroll 4
+	for (int ks = ks0; ks < ks1; ks++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(4 * ks + lq), fb(4 * ks + lq), c, 0, 0, 0);
+	return c;
+}
+
+__global__ __launch_bounds__(1024) void chol_wide_kernel(const CholWideArgs a) {
 	__shared__ double Gd[64 * 68];                       // G12: Gd[k * 68 + j]; later Z11 by columns: Cs[k * 68 + i] = Z11[i][k]
 	__shared__ double Rs[64 * 68];                       // R12: Rs[i * 68 + j]; later T = R12 Z22
-	__shared__ double dg[128], red[8];
+	__shared__ double G2s[10 * 256];                     // G22' in chol_body16's tile order, fp64 accumulator layout
+	__shared__ double dg[128], red[32];
 	__shared__ unsigned verdict[2];
 	const int t = threadIdx.x;
 	const int n2 = a.n - 64, NT2 = (n2 + 15) / 16;
 	auto reject = [&]() {
 		if (t == 0) {
 			a.status[0] = 1u; a.status[1] = 0u; a.status[2] = 0u;
-			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); hs[0] = 1u; }
+			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
 		}
 	};
 	if (a.prev_status && a.prev_status[0] != 0) { reject(); return; }
 	const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
 	const double min_diag = rows * 0x1p-90;
-	// the inputs of the later phases are requested now: their latency hides behind the first factorisation
-	double gin[16], g2in[10], dgin = 0.0;
+	const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+	const int ti = w >> 2, tj = w & 3, li = l & 15, lq = l >> 4;      // this wave's output tile; lane -> column li, rows lq + 4 reg
+	// G12, G22 and the diagonal are requested now: their latency hides behind the first factorisation
+	double gin[4], g2v[4] = {0.0, 0.0, 0.0, 0.0}, dgin = 0.0;
 #pragma unroll
-	for (int u = 0; u < 16; u++) gin[u] = a.gsum[WIDE_G12 + t + 256 * u];
+	for (int u = 0; u < 4; u++) gin[u] = a.gsum[WIDE_G12 + t + 1024 * u];
+	if (ti <= tj) {                                      // tile (ti, tj) of G22 in the Gram pass's fp32 accumulator order: row lq + 4 reg -> (reg' = lq, lane' = 16 reg + li)
 #pragma unroll
-	for (int u = 0; u < 10; u++) g2in[u] = a.gsum[WIDE_G22 + t + 256 * u];
+		for (int reg = 0; reg < 4; reg++) g2v[reg] = a.gsum[WIDE_G22 + tri4(ti, tj) * 256 + lq * 64 + 16 * reg + li];
+	}
 	if (t < 128) {                                       // original diagonal: tile (d, d), row = col = 16 d + c -> reg = c & 3, lane = 16 (c >> 2) + c
 		const int blk = t >> 6, j = t & 63, d = j >> 4, cc = j & 15;
 		dgin = a.gsum[(blk ? WIDE_G22 : 0) + tri4(d, d) * 256 + (cc & 3) * 64 + 16 * (cc >> 2) + cc];
 	}
 	// ---- block 1: R11, Z11 (fp64 image stays in LDS) ----
-	double* Zi = nullptr;                                // chol_body's LDS image of inverse(R): Zi[K * 65 + j] = Z[j][K]
-	chol_body(a.r, a.ldr, a.zf1, a.st1, nullptr, PtrLoad{a.gsum}, 64, 4, 1, 0.03125f, INFINITY, 0.0, min_diag, &Zi);
-	if (t == 0) verdict[0] = a.st1[0];                   // (written by this very thread inside chol_body)
+	double* Zi = nullptr;                                // chol_body16's LDS image of inverse(R): Zi[K * 65 + j] = Z[j][K], zero for j > K
+	chol_body16(a.r, a.ldr, a.zf1, a.st1, nullptr, PtrLoad{a.gsum}, 64, 4, 1, 0.03125f, INFINITY, 0.0, min_diag, &Zi);
+	if (t == 0) verdict[0] = a.st1[0];                   // (written by this very thread inside chol_body16)
 	if (t < 128) dg[t] = dgin;
 #pragma unroll
-	for (int u = 0; u < 16; u++) {
-		const int e = t + 256 * u;
-		const int tile = e >> 8, reg = (e >> 6) & 3, l = e & 63;
-		Gd[(16 * (tile >> 2) + 4 * (l >> 4) + reg) * 68 + 16 * (tile & 3) + (l & 15)] = gin[u];
+	for (int u = 0; u < 4; u++) {
+		const int e = t + 1024 * u;
+		const int tile = e >> 8, reg = (e >> 6) & 3, ll = e & 63;
+		Gd[(16 * (tile >> 2) + 4 * (ll >> 4) + reg) * 68 + 16 * (tile & 3) + (ll & 15)] = gin[u];
 	}
 	__syncthreads();
 	if (verdict[0] != 0) { reject(); return; }
 	// ---- Schur complement: R12 = Z11^T G12, G22' = G22 - R12^T R12 ----
-	const int ib = t >> 4, jb = t & 15;
-	double acc[4][4];
+	{
+		// R12[i][j] = sum_{k <= i} Z11[k][i] G12[k][j];  Z11[k][i] = Zi[i * 65 + k]
+		const f64x4 c = tile_product_f64([&](int k) { return Zi[(16 * ti + li) * 65 + k]; }, [&](int k) { return Gd[k * 68 + 16 * tj + li]; }, 0, 4 * (ti + 1), lq);
 #pragma unroll
-	for (int x = 0; x < 4; x++)
-#pragma unroll
-		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
-#pragma unroll 4
-	for (int k = 0; k <= 4 * ib + 3; k++) {              // R12[i][j] = sum_{k <= i} Z11[k][i] G12[k][j];  Z11[k][i] = Zi[i * 65 + k]
-		double zi[4], gj[4];
-#pragma unroll
-		for (int x = 0; x < 4; x++) { zi[x] = Zi[(4 * ib + x) * 65 + k]; gj[x] = Gd[k * 68 + 4 * jb + x]; }
-#pragma unroll
-		for (int x = 0; x < 4; x++)
-#pragma unroll
-			for (int y = 0; y < 4; y++) acc[x][y] = fma(zi[x], gj[y], acc[x][y]);
-	}
-#pragma unroll
-	for (int x = 0; x < 4; x++)
-#pragma unroll
-		for (int y = 0; y < 4; y++) {
-			const int i = 4 * ib + x, j = 4 * jb + y;
-			const double v = (j < n2) ? acc[x][y] : 0.0;
+		for (int reg = 0; reg < 4; reg++) {
+			const int i = 16 * ti + lq + 4 * reg, j = 16 * tj + li;
+			const double v = (j < n2) ? c[reg] : 0.0;
 			Rs[i * 68 + j] = v;
 			if (j < n2) a.r[(size_t)(64 + j) * a.ldr + i] = (float)v;
 		}
+	}
 	lds_barrier();                                       // R12 complete; every wave is done with G12
 	double* Cs = Gd;
-	for (int e = t; e < 64 * 64; e += 256) Cs[(e >> 6) * 68 + (e & 63)] = Zi[(e >> 6) * 65 + (e & 63)];   // Z11 survives the second factorisation here
-	{
-		// -sum_i R12[i][x] R12[i][y] for this thread's 4 x 4 block, scattered to the tile layout through global scratch (2560 doubles)
-		if (ib <= jb) {
+	for (int e = t; e < 64 * 64; e += 1024) Cs[(e >> 6) * 68 + (e & 63)] = Zi[(e >> 6) * 65 + (e & 63)];   // Z11 survives the second factorisation here
+	if (ti <= tj && tj < NT2) {
+		const f64x4 c = tile_product_f64([&](int i) { return Rs[i * 68 + 16 * ti + li]; }, [&](int i) { return Rs[i * 68 + 16 * tj + li]; }, 0, 16, lq);
 #pragma unroll
-			for (int x = 0; x < 4; x++)
-#pragma unroll
-				for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
-#pragma unroll 4
-			for (int i = 0; i < 64; i++) {
-				double rx[4], ry[4];
-#pragma unroll
-				for (int x = 0; x < 4; x++) { rx[x] = Rs[i * 68 + 4 * ib + x]; ry[x] = Rs[i * 68 + 4 * jb + x]; }
-#pragma unroll
-				for (int x = 0; x < 4; x++)
-#pragma unroll
-					for (int y = 0; y < 4; y++) acc[x][y] = fma(rx[x], ry[y], acc[x][y]);
-			}
-#pragma unroll
-			for (int x = 0; x < 4; x++)
-#pragma unroll
-				for (int y = 0; y < 4; y++) {
-					const int row = 4 * ib + x, col = 4 * jb + y;
-					const int ti = row >> 4, tj = col >> 4;
-					if (row <= col) {
-						const int tile = tri4(ti, tj);
-						a.g2[tile * 256 + (row & 3) * 64 + 16 * ((row & 15) >> 2) + (col & 15)] = -acc[x][y];
-						if (ti == tj) a.g2[tile * 256 + (col & 3) * 64 + 16 * ((col & 15) >> 2) + (row & 15)] = -acc[x][y];
-					}
-				}
-		}
-		__syncthreads();                                 // (global scratch written by other waves of this workgroup: full barrier)
-		// G22' = G22 + (-R12^T R12), repacked in place to chol_body's order (the tiles ti <= tj < NT2 row by row): thread t only
-		// touches position t of every tile and a packed index never exceeds the source index, so a target was read before
-		int ti = 0, tj = 0;
-#pragma unroll
-		for (int u = 0; u < 10; u++) {
-			const double v = g2in[u] + a.g2[u * 256 + t];
-			if (tj < NT2) a.g2[(ti * NT2 - (ti * (ti - 1)) / 2 + (tj - ti)) * 256 + t] = v;
-			if (++tj == 4) { ti++; tj = ti; }
-		}
+		for (int reg = 0; reg < 4; reg++) G2s[(ti * NT2 - (ti * (ti - 1)) / 2 + (tj - ti)) * 256 + reg * 64 + l] = g2v[reg] - c[reg];
 	}
-	// ---- block 2: R22, Z22 ----
-	chol_body(a.r + 64 * a.ldr + 64, a.ldr, a.zf2, a.st2, nullptr, PtrLoad{a.g2}, n2, NT2, 1, 0.03125f, INFINITY, 0.0, min_diag, &Zi);
+	lds_barrier();                                       // G22' complete; every wave is done with the image of Z11
+	// ---- block 2: R22, Z22 (the same instantiation of chol_body16 as block 1, i.e. the same LDS arrays) ----
+	chol_body16(a.r + 64 * a.ldr + 64, a.ldr, a.zf2, a.st2, nullptr, PtrLoad{G2s}, n2, NT2, 0, 0.03125f, INFINITY, 0.0, min_diag, &Zi);
 	if (t == 0) verdict[1] = a.st2[0];
 	__syncthreads();
 	if (verdict[1] != 0) { reject(); return; }
 	// ---- Z12 = -Z11 (R12 Z22), the 128 x 128 Z, the verdict over both blocks ----
-#pragma unroll
-	for (int x = 0; x < 4; x++)
-#pragma unroll
-		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
-#pragma unroll 4
-	for (int x = 0; x <= 4 * jb + 3; x++) {              // T[i][y] = sum_{x <= y} R12[i][x] Z22[x][y];  Z22[x][y] = Zi[y * 65 + x]
-		double ri[4], zy[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) { ri[u] = Rs[(4 * ib + u) * 68 + x]; zy[u] = Zi[(4 * jb + u) * 65 + x]; }
-#pragma unroll
-		for (int u = 0; u < 4; u++)
-#pragma unroll
-			for (int v = 0; v < 4; v++) acc[u][v] = fma(ri[u], zy[v], acc[u][v]);
-	}
+	// T[i][y] = sum_{x <= y} R12[i][x] Z22[x][y];  Z22[x][y] = Zi[y * 65 + x] (rows y >= n2 of the image are stale: they only reach
+	// columns y >= n2 of T and of Z12, which are not stored)
+	const f64x4 tt = tile_product_f64([&](int x) { return Rs[(16 * ti + li) * 68 + x]; }, [&](int x) { return Zi[(16 * tj + li) * 65 + x]; }, 0, 4 * (tj + 1), lq);
 	double s_acc = 0.0;
 	float ratio = 1.0f;
-	for (int e = t; e < 64 * 64; e += 256) {
+	for (int e = t; e < 64 * 64; e += 1024) {
 		const int j = e & 63, K = e >> 6;                // Z[j][K] of either block
 		const double z1 = Cs[K * 68 + j];
 		const double z2 = (K < n2) ? Zi[K * 65 + j] : 0.0;
@@ -400,43 +358,32 @@ __global__ __launch_bounds__(256) void chol_wide_kernel(const CholWideArgs a) {
 	}
 	lds_barrier();
 #pragma unroll
-	for (int u = 0; u < 4; u++)
-#pragma unroll
-		for (int v = 0; v < 4; v++) Rs[(4 * ib + u) * 68 + 4 * jb + v] = acc[u][v];     // T[k][y]
+	for (int reg = 0; reg < 4; reg++) Rs[(16 * ti + lq + 4 * reg) * 68 + 16 * tj + li] = tt[reg];     // T[k][y]
 	lds_barrier();
+	{
+		// Z12[i][y] = - sum_{k >= i} Z11[i][k] T[k][y];  Z11[i][k] = Cs[k * 68 + i]
+		const f64x4 c = tile_product_f64([&](int k) { return Cs[k * 68 + 16 * ti + li]; }, [&](int k) { return Rs[k * 68 + 16 * tj + li]; }, 4 * ti, 16, lq);
 #pragma unroll
-	for (int x = 0; x < 4; x++)
-#pragma unroll
-		for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
-#pragma unroll 4
-	for (int k = 4 * ib; k < 64; k++) {                  // Z12[i][y] = - sum_{k >= i} Z11[i][k] T[k][y]
-		double zi[4], ty[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) { zi[u] = Cs[k * 68 + 4 * ib + u]; ty[u] = Rs[k * 68 + 4 * jb + u]; }
-#pragma unroll
-		for (int u = 0; u < 4; u++)
-#pragma unroll
-			for (int v = 0; v < 4; v++) acc[u][v] = fma(-zi[u], ty[v], acc[u][v]);
-	}
-#pragma unroll
-	for (int u = 0; u < 4; u++)
-#pragma unroll
-		for (int v = 0; v < 4; v++) {
-			const int i = 4 * ib + u, y = 4 * jb + v;
-			const double z = (y < n2) ? acc[u][v] : 0.0;
-			a.zw[(size_t)(64 + y) * 128 + i] = (float)z;
-			s_acc = fma(dg[i] * z, z, s_acc);
+		for (int reg = 0; reg < 4; reg++) {
+			const int i = 16 * ti + lq + 4 * reg, y = 16 * tj + li;
+			const double zz = (y < n2) ? -c[reg] : 0.0;
+			a.zw[(size_t)(64 + y) * 128 + i] = (float)zz;
+			s_acc = fma(dg[i] * zz, zz, s_acc);
 		}
-	for (int e = t; e < 64 * n2; e += 256) {             // R below the diagonal blocks: rows 64.., columns < 64
+	}
+	for (int e = t; e < 64 * n2; e += 1024) {            // R below the diagonal blocks: rows 64.., columns < 64
 		const int i = e % n2, j = e / n2;
 		a.r[(size_t)j * a.ldr + 64 + i] = 0.0f;
 	}
 	for (int o = 32; o > 0; o >>= 1) { s_acc += __shfl_xor(s_acc, o); ratio = fminf(ratio, __shfl_xor(ratio, o)); }
-	if ((t & 63) == 0) { red[t >> 6] = s_acc; red[4 + (t >> 6)] = (double)ratio; }
+	if ((t & 63) == 0) { red[t >> 6] = s_acc; red[16 + (t >> 6)] = (double)ratio; }
 	lds_barrier();
 	if (t == 0) {
-		const float scond = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)a.n);
-		const float rmin = fminf(fminf((float)red[4], (float)red[5]), fminf((float)red[6], (float)red[7]));
+		double ssum = 0.0;
+		float rmin = 1.0f;
+#pragma unroll
+		for (int k = 0; k < 16; k++) { ssum += red[k]; rmin = fminf(rmin, (float)red[16 + k]); }
+		const float scond = (float)(ssum / (double)a.n);
 		const float max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
 		const unsigned s0 = (rmin > 0.03125f && scond <= max_scond) ? 0u : 1u;       // NaN compares false -> rejected
 		a.status[0] = s0;
@@ -446,7 +393,6 @@ __global__ __launch_bounds__(256) void chol_wide_kernel(const CholWideArgs a) {
 			volatile unsigned* hs = a.host_status;
 			hs[1] = __builtin_bit_cast(unsigned, rmin);
 			hs[2] = __builtin_bit_cast(unsigned, scond);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 			hs[0] = s0;
 		}
 	}
