@@ -1,4 +1,4 @@
-"""GPU tests of chol_kernel (tsqr_gpu_amd/csrc/tsqr_kernels.hip), the n x n step between the Gram pass and the apply pass:
+"""GPU tests of chol16_kernel (tsqr_gpu_amd/csrc/tsqr_kernels.hip), the n x n step between the Gram pass and the apply pass:
 R = chol(G), Z = inverse(R), accept / reject verdict -- the role of the reference's root tile QR (src/tsqr.cu:1164-1172).
 Checked against numpy fp64 Cholesky and inverse for both accumulator layouts the Gram kernels produce, ragged n, the shifted
 variant and the reject paths."""
@@ -40,23 +40,8 @@ def pack_tiles(g, n, f32_layout):
     return np.concatenate(out)
 
 
-W16 = False         # module switch set by the `variant` fixture: the selftest entry launches chol16_kernel when reps >= 1000
-
-
-@pytest.fixture(params=["chol_kernel (4 waves)", "chol16_kernel (16 waves)"], autouse=True)
-def variant(request):
-    """every test runs against both launches of the step: four waves (chol_body: also inside chol_wide_kernel) and sixteen waves
-    (chol_body16: what the 64-column path launches)"""
-    global W16
-    W16 = request.param.startswith("chol16")
-    yield request.param
-    W16 = False
-
-
 def run(st, g, n, level=1, rows=1 << 20, ldr=None, reps=0):
     """level 2 packs the tiles in the f32 accumulator layout, levels 1 / 3 in the f64 layout (what each Gram kernel writes)"""
-    if W16:
-        reps += 1000
     f32_layout = 1 if level == 2 else 0
     L, torch = st
     nt = (n + 15) // 16
@@ -152,5 +137,5 @@ def test_timing_report(st):
     g, _ = spd(64, 3.0, 1)
     for n in (16, 32, 48, 64):
         ms = run(st, g[:n, :n], n, level=2, reps=50)[5]
-        print("%s n=%d: %.2f us per launch (back to back; diagnostic build with time stamps)" % ("chol16_kernel" if W16 else "chol_kernel", n, ms * 1e3))
+        print("%s n=%d: %.2f us per launch (back to back; diagnostic build with time stamps)" % ("chol16_kernel", n, ms * 1e3))
     assert ms < 0.05

@@ -65,6 +65,30 @@ def test_parity_with_oracle(bq, oracle, torch_cuda, m, n, mode):
     assert np.abs(qn - qon).max() < PAR_TOL * scale
 
 
+@pytest.mark.parametrize("m", [128, 256, 384, 640, 128 * 17, 128 * 512, 128 * 513, 128 * 1025, 128 * 1538])
+def test_block_pattern_gram_kernel_against_the_chunk_kernel(bq, oracle, torch_cuda, m):
+    """Full 64-column matrices with m % 128 == 0 and 16-byte aligned columns take gram_blk_kernel (block-pattern loads, LDS staging),
+    everything else gram_bf16_kernel: the same matrix through both (lda = m and lda = m + 4 against lda = m + 1, which is not
+    aligned) must give the same R up to the summation order of the fp64 totals, for every loop shape of the new kernel -- fewer
+    blocks than workgroups, one / two / three blocks per workgroup, an odd block count in the last round."""
+    md = bq.compute_mode.fp32_tc_cor
+    a = oracle.uniform_matrix(m, 64, seed=m)
+    out = {}
+    bq.set_policy(bq.POLICY_GRAM_BF16)                              # (a 128 x 64 matrix is too short for the auto policy's bf16 level)
+    try:
+        for pad in (0, 4, 1):
+            st, q, r = run_gpu(bq, torch_cuda, a, md, False, lda_pad=pad, ldq_pad=3)
+            assert st == bq.success_factorization and bq.last_engine() == 3, (pad, st, bq.last_engine())
+            assert oracle.residual(a, q, r) < RES_TOL and oracle.orthogonality_fro(q) < ORTH_TOL * (1 if m >= 1024 else 10)
+            out[pad] = r
+    finally:
+        bq.set_policy(bq.POLICY_AUTO)
+    scale = np.abs(out[1]).max()
+    for pad in (0, 4):
+        assert np.abs(out[pad] - out[1]).max() <= 2e-6 * scale, (pad, np.abs(out[pad] - out[1]).max() / scale)
+    assert np.array_equal(out[0], out[4])                           # same kernel, same order: bit-identical
+
+
 @pytest.mark.parametrize("m,n", [(9211, 51), (4096, 128), (9000, 100), (5000, 200)])
 @pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
 def test_parity_with_oracle_reorth(bq, oracle, torch_cuda, m, n, mode):

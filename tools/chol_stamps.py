@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-kernel time stamps of the Cholesky step (libtsqr_selftest.so is built with -DTSQR_CHOL_STAMPS): per-group breakdown in shader
-cycles for the owner wave, the next owner and the others.  usage: chol_stamps.py [n] [w16=0|1]"""
+cycles for the first four groups of chol16_kernel (the stamp table has four wave rows).  usage: chol_stamps.py [n]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,26 +8,23 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 import test_gpu_chol as tc
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-w16 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 L = ctypes.CDLL(os.path.join(tc.ROOT, "tsqr_gpu_amd", "csrc", "libtsqr_selftest.so"))
 L.tsqr_selftest_chol_stamps.restype = ctypes.c_int
 L.tsqr_selftest_chol_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
 g, _ = tc.spd(n, 3.0, 1)
 nt = (n + 15) // 16
 gs = torch.from_numpy(tc.pack_tiles(g, n, 1)).cuda()
 r = torch.zeros(n * n, device="cuda"); z = torch.zeros(256 * nt * nt, device="cuda"); st = torch.zeros(4, dtype=torch.int32, device="cuda")
 out = torch.zeros(4 * 160, dtype=torch.int64, device="cuda")
-rc = L.tsqr_selftest_chol_stamps(out.data_ptr(), r.data_ptr(), n, z.data_ptr(), st.data_ptr(), gs.data_ptr(), n, nt, 2, float(1 << 20), w16)
+rc = L.tsqr_selftest_chol_stamps(out.data_ptr(), r.data_ptr(), n, z.data_ptr(), st.data_ptr(), gs.data_ptr(), n, nt, 2, float(1 << 20))
 assert rc == 0, rc
 s = out.cpu().numpy().reshape(4, 160)
 clk = (s[0, 3] - s[0, 0]) / max(1, (s[0, 4] - s[0, 5])) * 100.0      # MHz: shader cycles per 100 MHz tick
-print(("chol16_kernel" if w16 else "chol_kernel") + " n=%d: kernel body %d cycles (wave 0), clock ~%.0f MHz => %.2f us" % (n, s[0, 3] - s[0, 0], clk, (s[0, 3] - s[0, 0]) / clk))
+print("chol16_kernel n=%d: kernel body %d cycles (wave 0), clock ~%.0f MHz => %.2f us" % (n, s[0, 3] - s[0, 0], clk, (s[0, 3] - s[0, 0]) / clk))
 print("prologue (start -> first group) %d   elimination %d   epilogue (verdict, images out) %d" % (s[0, 1] - s[0, 0], s[0, 2] - s[0, 1], s[0, 3] - s[0, 2]))
 print("group: owner section | barrier wait of the owner / of another wave | updates after the barrier (owner / another wave) | period")
-for gi in range((n + 3) // 4):
-    if w16 and gi > 3:
-        break                                    # (the stamp table has four wave rows: groups 0..3 of the sixteen-wave form)
+for gi in range(min(4, (n + 3) // 4)):
     U = gi % 4; oth = (U + 2) % 4
     b = 8 + 8 * gi
     o, x = s[U], s[oth]

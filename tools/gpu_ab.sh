@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 i=0
 for v in "$@"; do
 	[ "$v" = "-" ] && v=""
-	for rep in 1 2; do
+	for rep in $(seq 1 ${REPS:-2}); do
 		env $v timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/ab_${i}_${rep}.json 2> gpurun_out/ab_${i}_${rep}.err || { echo "bench failed for [$v]"; tail -5 gpurun_out/ab_${i}_${rep}.err; exit 1; }
 		python - "$v" gpurun_out/ab_${i}_${rep}.json <<'PY'
 import json, sys

@@ -57,7 +57,7 @@ int tsqr_selftest_mfma_bf16(float* d, const float* a, const float* b) { hipLaunc
 int tsqr_selftest_split(float* out, const float* in, int n) { hipLaunchKernelGGL(split_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, out, in, n); return (int)hipDeviceSynchronize(); }
 }
 
-// ---- chol_kernel on summed Gram tiles (the step between the two streaming passes): one launch (results) + `reps` timed launches.
+// ---- chol16_kernel on summed Gram tiles (the step between the two streaming passes): one launch (results) + `reps` timed launches.
 // level 2: tiles in the f32 accumulator layout (bf16-split Gram pass), 1 / 3: f64 accumulator layout (fp64 Gram pass, 3 = shifted)
 extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT,
                                     int level, double rows, int reps) {
@@ -66,13 +66,7 @@ extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* st
 	a.rows = rows; a.shift_coef = (level == 3) ? 11.0 * 1.1102230246251565e-16 : 0.0; a.n = n; a.NT = NT; a.level = level; a.scond_floor = 4.0f;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	// reps >= 1000: the sixteen-wave form (chol16_kernel) with reps % 1000 timed launches
-	const bool w16 = reps >= 1000;
-	reps %= 1000;
-	auto launch = [&]() {
-		if (w16) hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, 0, a);
-		else hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a);
-	};
+	auto launch = [&]() { hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, 0, a); };
 	launch();
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++) launch();
@@ -86,19 +80,16 @@ extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* st
 }
 
 
-// ---- in-kernel time stamps of chol_kernel (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----
+// ---- in-kernel time stamps of chol16_kernel (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----
 extern "C" int tsqr_selftest_chol_stamps(unsigned long long* out_dev, float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT,
-                                         int level, double rows, int w16) {
+                                         int level, double rows) {
 #ifdef TSQR_CHOL_STAMPS
 	tsqrmi::CholArgs a{};
 	a.r = r; a.ldr = ldr; a.z = z; a.status = status; a.host_status = nullptr; a.gsum = gsum; a.prev_status = nullptr; a.rows_dev = nullptr;
 	a.rows = rows; a.shift_coef = 0.0; a.n = n; a.NT = NT; a.level = level; a.scond_floor = 4.0f;
 	unsigned long long* null_out = nullptr;
 	hipMemcpyToSymbol(HIP_SYMBOL(tsqrmi::g_chol_stamp_out), &null_out, sizeof(null_out));
-	auto launch = [&]() {
-		if (w16) hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, 0, a);
-		else hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, 0, a);
-	};
+	auto launch = [&]() { hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, 0, a); };
 	for (int i = 0; i < 20; i++) launch();               // warm: clocks, instruction cache
 	hipMemcpyToSymbol(HIP_SYMBOL(tsqrmi::g_chol_stamp_out), &out_dev, sizeof(out_dev));
 	launch();
@@ -249,6 +240,63 @@ extern "C" float tsqr_selftest_mfma_f64_rate(double* out, int wgs, int iters) {
 	(void)hipEventElapsedTime(&ms, e0, e1);
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	return ms;
+}
+
+// ---- do vector instructions issue in the shadow of MFMAs?  Per iteration ten independent v_mfma_f32_16x16x32_bf16 and / or thirty
+// independent vector instructions (v_pk_add_f32, v_cvt_pk_bf16_f32 + v_and), interleaved 1 : 3 or in two blocks; shader cycles
+// (s_memtime) per iteration of wave 0.  mode 0 MFMA only, 1 vector only, 2 interleaved, 3 blocks ----
+template <int MODE>
+__global__ __launch_bounds__(256) void issue_overlap_kernel(float* out, unsigned long long* cyc, int iters) {
+	tsqrmi::f32x4 acc[10];
+#pragma unroll
+	for (int t = 0; t < 10; t++) acc[t] = tsqrmi::f32x4{0.f, 0.f, 0.f, 0.f};
+	tsqrmi::bf16x8 a, b;
+	{
+		tsqrmi::u32x4 ua = {threadIdx.x * 3u + 1u, threadIdx.x, 7u, 9u}, ub = {threadIdx.x * 5u + 2u, 1u, threadIdx.x, 3u};
+		a = __builtin_bit_cast(tsqrmi::bf16x8, ua); b = __builtin_bit_cast(tsqrmi::bf16x8, ub);
+	}
+	tsqrmi::f32x2_t x[10], y[10];
+	unsigned z[10];
+#pragma unroll
+	for (int i = 0; i < 10; i++) { x[i] = tsqrmi::f32x2_t{1.0f + threadIdx.x, 2.0f + i}; y[i] = tsqrmi::f32x2_t{1e-3f * i, 1e-4f}; z[i] = i; }
+	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+	for (int it = 0; it < iters; it++) {
+		if (MODE != 1) {
+#pragma unroll
+			for (int t = 0; t < 10; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+		}
+		if (MODE != 0) {
+#pragma unroll
+			for (int i = 0; i < 10; i++) {
+				x[i] = x[i] + y[i];                                  // v_pk_add_f32
+				const unsigned h = tsqrmi::cvt_pk_bf16(x[i][0], x[i][1]);    // v_cvt_pk_bf16_f32
+				z[i] = (z[i] & 0xffff0000u) ^ h;                     // v_and_or / v_bfi-like
+			}
+		}
+		if (MODE == 2) {
+#pragma unroll
+			for (int t = 0; t < 10; t++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+		}
+		if (MODE == 3) {
+			__builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+			__builtin_amdgcn_sched_group_barrier(0x002, 40, 0);
+		}
+	}
+	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+	float sum = 0.f;
+#pragma unroll
+	for (int t = 0; t < 10; t++) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3] + x[t][0] + x[t][1] + (float)z[t];
+	if (sum == 123.456f) out[0] = sum;
+	if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+extern "C" int tsqr_selftest_issue_overlap(float* out, unsigned long long* cyc, int mode, int wgs, int iters) {
+	switch (mode) {
+		case 0: hipLaunchKernelGGL(issue_overlap_kernel<0>, dim3(wgs), dim3(256), 0, 0, out, cyc, iters); break;
+		case 1: hipLaunchKernelGGL(issue_overlap_kernel<1>, dim3(wgs), dim3(256), 0, 0, out, cyc, iters); break;
+		case 2: hipLaunchKernelGGL(issue_overlap_kernel<2>, dim3(wgs), dim3(256), 0, 0, out, cyc, iters); break;
+		default: hipLaunchKernelGGL(issue_overlap_kernel<3>, dim3(wgs), dim3(256), 0, 0, out, cyc, iters); break;
+	}
+	return (int)hipDeviceSynchronize();
 }
 
 // ---- LDS bank behaviour of ds_read_b128: lane l = 16 q + c reads 16 bytes at dword (A c + B q); run under

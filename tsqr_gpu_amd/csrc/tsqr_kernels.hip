@@ -618,12 +618,12 @@ __global__ __launch_bounds__(64 * FOLD_COOP_WAVES) void fold_coop_kernel(const F
 // ---------------------------------------------------------------------------------------------
 // Gram engine (R-factor engine of fp32_tc_cor):  G = A^T A on the fp64 matrix cores, R = chol(G) in fp64.
 // Products of fp32 inputs are exact in fp64 and the accumulation is fp64, so R is as backward-accurate as an fp32
-// Householder R while cond(A)^2 * 2^-53 * n << 1; chol_kernel reports breakdown and the host falls back to fold_kernel.
+// Householder R while cond(A)^2 * 2^-53 * n << 1; chol16_kernel reports breakdown and the host falls back to fold_kernel.
 //   gram_kernel        : every wave accumulates the upper-triangular 16x16 tiles of its strip's Gram matrix with
 //                        v_mfma_f64_16x16x4_f64 (both operands straight from the (c,q) registers), the four waves of a
 //                        workgroup are summed through LDS, one partial per workgroup goes to HBM.
 //   gram_reduce_kernel : partials -> NSPLIT sub-sums per entry (fixed order: deterministic).
-//   chol_kernel        : sub-sums -> G (LDS, fp64) -> R (fp32, user layout), Z = inverse(R) (fp32, NP x NP), status.
+//   chol16_kernel      : sub-sums -> G (LDS, fp64) -> R (fp32, user layout), Z = inverse(R) (fp32, NP x NP), status.
 // ---------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 // (six exact-product terms per tile).  Every K-step (32 rows) is one MFMA chain that starts from zero; its fp32 result is
 // added to fp64 totals on the vector units, so the only fp32 roundings are those inside one chain and they average out over
 // the K-steps (2^20 rows: U(0,1) input 5.5e-7 instead of 9.2e-7, U(0,1)+10 1.5e-5 instead of 2e-4 with fp32 totals).
-// The host accepts the result only when the Cholesky pivots show nearly orthogonal columns (chol_kernel thresholds).
+// The host accepts the result only when the Cholesky pivots show nearly orthogonal columns (chol16_kernel thresholds).
 // Partials use the f32 MFMA C/D layout (row = 4*(lane>>4) + reg).
 // Measured alternatives (round 2, 2^20 x 64; tools/seq_bench.py, git history): a workgroup LDS-DMA ring (61 us: sharing a block
 // between waves duplicates the split), a per-wave LDS-DMA bounce with full-line requests and a prefetched next chunk (54.6 us)
@@ -816,6 +816,150 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	}
 }
 
+// gram_blk_kernel (round 3): the same Gram tiles for FULL 64-column matrices, with the block pattern of the apply pass on the load
+// side.  gram_bf16_kernel's (c,q) register layout feeds the MFMAs without any exchange, but an instruction of it can only ask for
+// 64 contiguous bytes per column (sixteen columns, four lanes each): its load-only skeleton takes 47.6 us at 2^20 x 64 where the
+// block pattern (512 contiguous bytes per column and instruction) takes 40 (tools/seq_bench.py).  Here a workgroup loads 128-row x
+// 64-column blocks in the block pattern, stages them as fp32 in LDS (double buffered: ONE LDS-only barrier per block), and wave w
+// takes the K-step of rows 32 w .. 32 w + 31 for ALL ten tile pairs: two ds_read_b128 per column tile (column stride 136 floats:
+// the eight lanes of a pass fall on different banks), the bf16 split of every element exactly once (by the wave that consumes it),
+// 60 MFMAs.  Two blocks per workgroup in flight in registers, rotated by unrolling (see gram_wide_kernel).
+// Totals as in gram_bf16_kernel: one MFMA chain per K-step, fp64 from there on; the ten accumulators are handled in two groups of
+// five (the first group is flushed while the second group's MFMAs run: twenty accumulator registers instead of forty -- the kernel
+// sits at 253 registers, two waves per SIMD).  (fp32 round-to-nearest wave totals, with fp64 only from the workgroup sum on, save
+// 40 registers and a third of the vector instructions, do not change the call time, and cost accuracy on same-sign inputs as the
+// rows per wave grow: U(0,1)+0.25 gives 9.5e-7 / 1.9e-6 / 2.4e-6 at 2^20 / 2^23 / 2^24 rows against 7.8e-7 / 9.5e-7 with fp64
+// totals -- tools/gram_accuracy.py, profiles/r03_experiment_log.md.)
+// Partials in the same format as gram_bf16_kernel.
+constexpr int GB_ROWS = 128, GB_RS = 136;
+constexpr int GB_LDS_BYTES = 2 * 64 * GB_RS * 4;
+__global__ __launch_bounds__(256, 2) void gram_blk_kernel(const GramArgs a) {
+	constexpr int NTRI = 10;
+	extern __shared__ __attribute__((aligned(16))) float gb_as[];        // [buffer][column][GB_RS]
+	static_assert(GB_LDS_BYTES >= (int)sizeof(double) * 2 * NTRI * 256, "the final workgroup reduction aliases the block buffers");
+	if (a.skip_status && a.skip_status[0] != 0) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int c = lane & 15, q = lane >> 4;
+	const int lcol = lane >> 5, lrow = 4 * (lane & 31);
+	const int nblk = a.nchunks, step = gridDim.x;        // 128-row blocks (the host sends only m % 128 == 0, n == 64, 16-byte aligned columns, lda < 2^23)
+	f64x4 tot[NTRI];
+#pragma unroll
+	for (int t = 0; t < NTRI; t++) tot[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+	// buffer loads: descriptor on the block (wave-uniform), ONE loop-invariant 32-bit per-thread offset, the column group in the
+	// scalar offset -- no 64-bit address arithmetic in vector registers.  (With flat loads the allocator took the eight address pairs
+	// of a set from registers of the set in flight and the waits it then has to insert drained the queue once per block.)
+	const unsigned voff = (unsigned)(((size_t)lcol * a.lda + lrow) * sizeof(float));
+	const unsigned soff0 = (unsigned)((size_t)(2 * wv) * a.lda * sizeof(float)), soffk = (unsigned)(8 * a.lda * sizeof(float));
+	auto load_block = [&](f32x4 (&v)[8], int b) {
+		// (no branch at all: past the end the last block is simply loaded again and never used)
+		const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a + (size_t)min(b, nblk - 1) * GB_ROWS), 0, -1, 0x00020000);
+#pragma unroll
+		for (int k = 0; k < 8; k++) v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff0 + k * soffk, 0));
+	};
+	auto stage = [&](const f32x4 (&v)[8], float* buf) {
+#pragma unroll
+		for (int k = 0; k < 8; k++) *reinterpret_cast<f32x4*>(&buf[(2 * wv + lcol + 8 * k) * GB_RS + lrow]) = v[k];
+	};
+	auto products = [&](const float* buf) {
+		bf16x8 oh[4], om[4], ol[4];
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const float* src = &buf[(16 * t + c) * GB_RS + 32 * wv + 8 * q];
+			const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+			u32x4 hh, mm, ll;
+			unsigned h, m, lo;
+			split3_pair(x0[0], x0[1], h, m, lo); hh[0] = h; mm[0] = m; ll[0] = lo;
+			split3_pair(x0[2], x0[3], h, m, lo); hh[1] = h; mm[1] = m; ll[1] = lo;
+			split3_pair(x1[0], x1[1], h, m, lo); hh[2] = h; mm[2] = m; ll[2] = lo;
+			split3_pair(x1[2], x1[3], h, m, lo); hh[3] = h; mm[3] = m; ll[3] = lo;
+			oh[t] = __builtin_bit_cast(bf16x8, hh);
+			om[t] = __builtin_bit_cast(bf16x8, mm);
+			ol[t] = __builtin_bit_cast(bf16x8, ll);
+		}
+		// tile pairs in the order of the partials, in two groups of five accumulators: (0,0) (0,1) (0,2) (0,3) (1,1) | (1,2) (1,3)
+		// (2,2) (2,3) (3,3); per pair six of the nine partial products, smallest first: mm hl lh hm mh hh (as gram_bf16_kernel).
+		// (A software-pipelined order -- split of tile t+1 interleaved with the MFMAs of the pairs that need only tiles <= t; vector
+		// instructions do issue in the shadow of MFMAs, tools/issue_overlap.py -- measured the same call time: not kept.)
+		static_for<0, 2>([&](auto gg) {
+			constexpr int g = decltype(gg)::value;
+			f32x4 acc[5];
+#pragma unroll
+			for (int i = 0; i < 5; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int pass = 3; pass < 9; pass++)
+				static_for<0, 5>([&](auto ii) {
+					constexpr int idx = 5 * g + decltype(ii)::value;
+					constexpr int ti = idx < 4 ? 0 : (idx < 7 ? 1 : (idx < 9 ? 2 : 3));
+					constexpr int tj = idx < 4 ? idx : (idx < 7 ? idx - 3 : (idx < 9 ? idx - 5 : 3));
+					const bf16x8 av = (pass == 4 || pass == 6 || pass == 8) ? oh[ti] : ((pass == 3 || pass == 7) ? om[ti] : ol[ti]);
+					const bf16x8 bv = (pass == 5 || pass == 7 || pass == 8) ? oh[tj] : ((pass == 3 || pass == 6) ? om[tj] : ol[tj]);
+					acc[idx - 5 * g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[idx - 5 * g], 0, 0, 0);
+				});
+#pragma unroll
+			for (int i = 0; i < 5; i++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) tot[5 * g + i][r] += (double)acc[i][r];
+		});
+	};
+	// register sets X, Y and two block buffers; the loop head sits between "stage the next block" and "barrier" (gram_wide_kernel)
+	constexpr int BUF = 64 * GB_RS;
+	f32x4 vx[8], vy[8];
+	int bi = blockIdx.x, it = 0;
+	load_block(vx, bi);
+	asm volatile("" ::: "memory");
+	load_block(vy, bi + step);
+	asm volatile("" ::: "memory");
+	if (bi < nblk) stage(vx, gb_as);
+	while (bi < nblk) {
+		lds_barrier();                                   // block `bi` is staged; every wave is done with the other buffer
+		load_block(vx, bi + 2 * step);
+		asm volatile("" ::: "memory");
+		products(gb_as + (it & 1) * BUF);
+		bi += step; it++;
+		if (bi >= nblk) break;
+		stage(vy, gb_as + (it & 1) * BUF);
+		lds_barrier();
+		load_block(vy, bi + 2 * step);
+		asm volatile("" ::: "memory");
+		products(gb_as + (it & 1) * BUF);
+		bi += step; it++;
+		if (bi >= nblk) break;
+		stage(vx, gb_as + (it & 1) * BUF);
+	}
+	// workgroup sum in fp64: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the partial
+	__syncthreads();
+	double* red = reinterpret_cast<double*>(gb_as);      // [2][NTRI * 256]
+	if (wv >= 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[(wv - 2) * NTRI * 256 + (t * 4 + r) * 64 + lane] = tot[t][r];
+	}
+	__syncthreads();
+	if (wv < 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) tot[t][r] += red[wv * NTRI * 256 + (t * 4 + r) * 64 + lane];
+	}
+	__syncthreads();
+	if (wv == 1) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[(t * 4 + r) * 64 + lane] = tot[t][r];
+	}
+	__syncthreads();
+	if (wv == 0) {
+		double* out = a.part + (size_t)blockIdx.x * NTRI * 256;
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) part_store(&out[(t * 4 + r) * 64 + lane], tot[t][r] + red[(t * 4 + r) * 64 + lane]);
+	}
+}
+
 // gram_reduce1_kernel: partials -> G in ONE launch (deterministic: fixed partition, fixed tree).  A workgroup owns 16
 // consecutive entries; thread (e = tid & 15, s = tid >> 4) sums the partials b = s, s+16, s+32, ... of entry e with four
 // independent accumulators, then the 16 s-sums of every entry are added through LDS in a fixed pairwise tree.
@@ -855,12 +999,9 @@ __global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ 
 	}
 }
 
-// chol_kernel: sub-sums -> G (fp64) -> R = chol(G) and M = R^-T by the same row operations (forward elimination of
-// [R^T | I]), all in fp64.  Thread (w = wave, j = lane) owns column j and the rows i = w + 4 s of both G and M in
-// registers; step k: the wave owning row k scales it with 1/sqrt(pivot) (v_rsq_f64 + two Newton steps) and publishes
-// the row through LDS (double buffered: one barrier per step), then every wave updates its rows i > k.
-// status[0]: 0 ok, 1 breakdown (a pivot fell below 2^-40 of its diagonal entry: cond(A)^2 is beyond fp64 Cholesky)
-// status[1]: bit pattern of the smallest pivot ratio (float) for diagnostics
+// The Cholesky step: sub-sums -> G (fp64) -> R = chol(G) and M = R^-T by the same row operations (forward elimination of
+// [R^T | I]), all in fp64; Z = inverse(R) = M^T.  chol_body16 below; chol16_kernel is its launch for the 64-column path,
+// chol_wide_kernel (tsqr_wide.hip) runs it twice inside one launch.
 __device__ __forceinline__ double bcast_lane_f64(double x, int lane_const) {
 	const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
 	const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, lane_const);
@@ -874,223 +1015,39 @@ __device__ __forceinline__ double bcast_lane_f64(double x, int lane_const) {
 __device__ unsigned long long* g_chol_stamp_out = nullptr;           // [4 waves][CHOL_NSTAMP] + [4] s_memrealtime pairs
 constexpr int CHOL_NSTAMP = 160;
 __shared__ unsigned long long chol_stamp_lds[4 * CHOL_NSTAMP];
-#define CHOL_STAMP(slot) do { if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define CHOL_STAMP16(slot) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
-#define CHOL_STAMP(slot) do {} while (0)
 #define CHOL_STAMP16(slot) do {} while (0)
 #endif
 typedef double f64x2c __attribute__((ext_vector_type(2)));
 
-// Row ownership of the elimination kernels: thread (w, j) holds column j of the rows  row(w, s) = 16*(s>>2) + 4*w + (s&3),
-// i.e. every wave owns FOUR consecutive rows of each 16-row block.  A "group" = those four rows: its owner factors them
-// against each other in registers (lane broadcasts, no LDS), publishes the four finished rows, and after ONE barrier all
-// waves apply the four rank-1 updates to their remaining rows.  16 barriers for 64 rows; after the four groups of a block
-// the register rows rotate by four so the active block is always slots 0..3.
-template <int U>
-__device__ __forceinline__ void chol_group(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* __restrict__ r, size_t ldr,
-                                           float* __restrict__ z, int NP, double* Zd,
-                                           double* pv, int w, int j, int n, int kk, double dgj, double& s_acc) {
-	const int K0 = 16 * kk + 4 * U;
-	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
-	double* rr = Rrow + (U & 1) * 256;                   // [4][64]
-	double* mr = Mrow + (U & 1) * 256;
-	CHOL_STAMP(8 + 8 * (4 * kk + U) + 0);
-	if (w == U) {
-		// the owner's section is the critical path (three waves wait at the barrier): nothing but the pivots, the two row
-		// scalings, the in-group eliminations and the publication of the rows; fp32 copies, Z and the verdict sums are taken
-		// from the published rows by a wave that is off the path (below)
-		static_for<0, 4>([&](auto uu) {
-			constexpr int u = decltype(uu)::value;
-			const int K = K0 + u;
-			const double piv0 = bcast_lane_f64(g[u], K);
-			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
-			double y = __builtin_amdgcn_rsq(piv);
-			y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);      // one Newton step (v_rsq_f64 is good to ~2^-23: 2^-45 after it)
-			const bool live = K < n;
-			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
-			const double mk = live ? mm[u] * y : 0.0;
-			static_for<u + 1, 4>([&](auto vv) {
-				constexpr int v = decltype(vv)::value;
-				const double rkv = bcast_lane_f64(rk, K0 + v);   // R[K][K0+v]
-				g[v] = fma(-rkv, rk, g[v]);
-				mm[v] = fma(-rkv, mk, mm[v]);
-			});
-			rr[u * 64 + j] = rk;
-			mr[u * 64 + j] = mk;
-			if (j == 0 && live) pv[K] = piv0;
-		});
-	}
-	CHOL_STAMP(8 + 8 * (4 * kk + U) + 1);
-	lds_barrier();                                       // (LDS only: the result stores below stay in flight across the groups)
-	CHOL_STAMP(8 + 8 * (4 * kk + U) + 2);
-	double rkj[4], mkc[4];
-#pragma unroll
-	for (int u = 0; u < 4; u++) { rkj[u] = rr[u * 64 + j]; mkc[u] = mr[u * 64 + j]; }
-	if (w == ((U + 3) & 3)) {                            // the previous owner: not the next one, which is on the critical path
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			const int K = K0 + u;
-			if (K < n) {
-				// the finished rows leave for global memory at once (round 3: the stores overlap the rest of the elimination instead
-				// of forming a 5 K-cycle tail): column K of Z = row K of M, contiguous; row K of R, strided by ldr, exact zeros
-				// below the diagonal
-				if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mkc[u] : 0.0f;     // Z[j][K] = M[K][j]
-				if (j < n) r[(size_t)j * ldr + K] = (j >= K) ? (float)rkj[u] : 0.0f;
-				Zd[K * 65 + j] = (j <= K) ? mkc[u] : 0.0;                            // (fp64 image, read on by chol_wide_kernel)
-				if (j <= K) s_acc = fma(dgj * mkc[u], mkc[u], s_acc);                // sum of g_jj * Z[j][K]^2
-			}
-		}
-	}
-	const int nlive = 16 - 4 * kk;                       // register rows that still exist
-#pragma unroll
-	for (int s = 0; s < 16; s++) {
-		if (s < nlive && !(s < 4 && w <= U)) {            // wave-uniform; slots 0..3 of waves <= U are finished rows
-			const int i = 16 * (kk + (s >> 2)) + 4 * w + (s & 3);
-			double acc_g = g[s], acc_m = mm[s];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const double rki = rr[u * 64 + i];           // R[K0+u][i]; rows i > K0+3 here
-				acc_g = fma(-rki, rkj[u], acc_g);
-				acc_m = fma(-rki, mkc[u], acc_m);
-			}
-			g[s] = acc_g; mm[s] = acc_m;
-		}
-	}
-	CHOL_STAMP(8 + 8 * (4 * kk + U) + 3);
-}
-
-// LOADG: functor e -> G tile entry e (accumulator order); host_status: optional device-visible alias of pinned host memory
-// that receives the three status words as well (the host then needs no copy operation to read them).
-template <class LOADG>
-__device__ __forceinline__ void chol_body(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
-                                          unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
-                                          float max_scond, double shift_coef = 0.0, double min_diag = 0.0, double** gs_out = nullptr) {
-	__shared__ double Gs[64 * 65];               // symmetric G (assembly); afterwards the fp64 image of Z: Gs[K * 65 + j] = Z[j][K]
-	if (gs_out) *gs_out = Gs;                    // (a caller in the same kernel may go on with that image: chol_wide_kernel)
-	__shared__ double Rrow[2 * 256], Mrow[2 * 256], dg[64], pv[64];
-	const int t = threadIdx.x;
-	const int j = t & 63, w = t >> 6;
-	const int NP = 16 * NT;
-	CHOL_STAMP(0);
-#ifdef TSQR_CHOL_STAMPS
-	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 5] = __builtin_amdgcn_s_memrealtime();
-#endif
-	// issue the loads of G first (one value per thread and tile), then initialise LDS while they are in flight
-	double gv[10];
-	{
-		int idx = 0;
-		for (int ti = 0; ti < 4; ti++)
-			for (int tj = ti; tj < 4; tj++) {
-				if (ti < NT && tj < NT) { gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = loadg(idx * 256 + t); idx++; }
-				else gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = 0.0;
-			}
-	}
-	if (NT < 4)                                          // with all ten tiles present every entry of Gs is written below
-		for (int i = t; i < 64 * 65; i += 256) Gs[i] = 0.0;
-	for (int e = n * NP + t; e < NP * NP; e += 256) z[e] = 0.0f;          // padding rows of Z
-	__syncthreads();
-	{
-		const int reg = t >> 6, l = t & 63;
-#pragma unroll
-		for (int ti = 0; ti < 4; ti++)
-#pragma unroll
-			for (int tj = ti; tj < 4; tj++) {
-				if (ti < NT && tj < NT) {
-					// C/D layouts: f64 MFMA row = (lane>>4) + 4*reg, f32/bf16 MFMA row = 4*(lane>>4) + reg; col = lane&15
-					const int row = 16 * ti + (f32_layout ? 4 * (l >> 4) + reg : (l >> 4) + 4 * reg);
-					const int col = 16 * tj + (l & 15);
-					const double v = gv[ti * 4 + tj - (ti * (ti + 1)) / 2];
-					// a diagonal tile holds (i,j) and (j,i); in the bf16-split Gram matrix they can differ by an ulp (cross terms
-					// are added in opposite order), so only the upper-triangle owner writes both mirror positions
-					if (row <= col) {
-						Gs[row * 65 + col] = v;
-						Gs[col * 65 + row] = v;
-					}
-				}
-			}
-	}
-	__syncthreads();
-	if (shift_coef > 0.0) {
-		// shifted Cholesky (Fukaya et al., "Shifted Cholesky QR for computing the QR factorization of ill-conditioned matrices",
-		// SIAM J. Sci. Comput. 2020): G + s I with s = shift_coef * trace(G) >= 11 (mn + n(n+1)) u ||A||_2^2 is safely positive
-		// definite for any fp32 input; the caller runs a second (unshifted) sweep on the resulting Q
-		if (w == 0) {
-			double tr = (j < n) ? Gs[j * 65 + j] : 0.0;
-			for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
-			if (j < n) Gs[j * 65 + j] += shift_coef * tr;
-		}
-		__syncthreads();
-	}
-	double g[16], mm[16];
-#pragma unroll
-	for (int s = 0; s < 16; s++) {
-		const int i = 16 * (s >> 2) + 4 * w + (s & 3);
-		g[s] = Gs[i * 65 + j];
-		mm[s] = (i == j) ? 1.0 : 0.0;
-	}
-	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; }
-	const double dgj = Gs[j * 65 + j];
-	double s_acc = 0.0;
-	__syncthreads();
-	CHOL_STAMP(1);
-#pragma unroll 1
-	for (int kk = 0; kk < 4; kk++) {
-		static_for<0, 4>([&](auto u) { chol_group<decltype(u)::value>(g, mm, Rrow, Mrow, r, ldr, z, NP, Gs, pv, w, j, n, kk, dgj, s_acc); });
-#pragma unroll
-		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
-	}
-	// scaled conditioning S = || D * inverse(R) ||_F^2 / n with D = diag(sqrt(g_jj)): 1 for orthogonal columns of any scaling,
-	// ~cond^2 of the column-scaled matrix otherwise.  An entry-wise error eps*sqrt(g_ii g_jj) of G perturbs Q^T Q by <= eps*n*S.
-	CHOL_STAMP(2);
-	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
-	__syncthreads();
-	if (j == 0) Rrow[w] = s_acc;
-	__syncthreads();
-	// status[0]: 0 ok, 1 rejected: a pivot fell below min_ratio of its diagonal entry (2^-40 for the fp64 Gram matrix:
-	//            cond(A)^2 beyond fp64 Cholesky; 2^-5 for the bf16-split Gram matrix) or S exceeds max_scond (bf16-split Gram
-	//            matrix only: its fp32 accumulation is good enough for nearly orthogonal columns only)
-	// status[1]: bit pattern of the smallest pivot ratio (float), status[2]: of S (float) -- diagnostics
-	if (w == 0) {
-		const double d0 = dg[j], p0 = pv[j];
-		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
-		// min_diag (bf16-split level): a column whose squared norm is so small that its fp32 products live near the denormal range
-		// was not accumulated accurately (measured: entries ~1e-22 gave ||Q^T Q - I|| = 1e-2) -> reject, the fp64 level is exact
-		if (j < n && !(d0 >= min_diag)) ratio = 0.0f;
-		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
-		if (j == 0) {
-			const float scond = (float)(((Rrow[0] + Rrow[1]) + (Rrow[2] + Rrow[3])) / (double)n);
-			const unsigned s0 = (ratio > min_ratio && scond <= max_scond) ? 0u : 1u;     // NaN compares false -> rejected
-			status[0] = s0;
-			status[1] = __builtin_bit_cast(unsigned, ratio);
-			status[2] = __builtin_bit_cast(unsigned, scond);
-			if (host_status) {
-				// (no fence: the host reads these words only after the completion word of a LATER kernel on the stream, or after a
-				// stream synchronisation -- a system-scope release here wrote back the whole L2 on the critical path of every call)
-				volatile unsigned* hs = host_status;
-				hs[1] = __builtin_bit_cast(unsigned, ratio);
-				hs[2] = __builtin_bit_cast(unsigned, scond);
-				hs[0] = s0;
-			}
-		}
-	}
-	// (R and Z have left for global memory row by row during the elimination: chol_group)
-	CHOL_STAMP(3);
-#ifdef TSQR_CHOL_STAMPS
-	if ((threadIdx.x & 63) == 0) chol_stamp_lds[(threadIdx.x >> 6) * CHOL_NSTAMP + 4] = __builtin_amdgcn_s_memrealtime();
-	__syncthreads();
-	if (g_chol_stamp_out)
-		for (int i = threadIdx.x; i < 4 * CHOL_NSTAMP; i += 256) g_chol_stamp_out[i] = chol_stamp_lds[i];
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------
-// chol_body16 (round 3): the same step on SIXTEEN waves -- wave w owns the four rows 4w .. 4w+3 of G and of M = R^-T, i.e. exactly
-// one group of four pivots.  Why: in-kernel stamps of chol_body (tools/chol_stamps.py) show that a group costs the owner's section
-// (~1.25 K cycles) PLUS the rank-4 update of every wave's 16 rows (128 fp64 FMAs = ~1.4 K cycles, one v_fma_f64 per ~10 cycles and
-// wave) before the next owner can start.  With one group per wave the update between two owner sections is four rows (32 FMAs),
-// no rows rotate, and the sixteen waves (four per SIMD) share the fp64 pipes for the updates.  Same arithmetic per entry, same
-// status words, same interface as chol_body.
+// chol_body16: the step on SIXTEEN waves -- thread (w = wave, j = lane) holds column j of the four rows 4w .. 4w+3 of G and of
+// M = R^-T, i.e. wave w owns exactly one "group" of four pivots.  The owner factors its four rows against each other in registers
+// (lane broadcasts, no LDS: v_rsq_f64 + one Newton step per pivot), publishes the four finished rows in LDS (double buffered), and
+// after ONE LDS-only barrier the waves behind it apply the rank-4 update to their rows -- the next owner as one straight-line block
+// with its own section, so that its update of M fills the latency gaps of the pivot chain.  A wave that is off the path streams the
+// finished rows of R and Z to global memory and grows the verdict sum.  Why sixteen waves: in-kernel stamps of the four-wave form of
+// rounds 1-2 (sixteen rows per wave; tools/chol_stamps.py, profiles/r03_experiment_log.md) showed a group costing the owner's
+// section (~1.25 K cycles) PLUS every wave's rank-4 update of 16 rows (128 fp64 FMAs = ~1.4 K cycles: a lone wave issues one
+// v_fma_f64 per ~10 cycles) before the next owner could start; with one group per wave that update is four rows, no rows rotate,
+// and the waves share the fp64 pipes four per SIMD: 19.2 -> 17.4 us in the call.
+//   LOADG      : functor e -> G tile entry e (accumulator order of the Gram pass: f32_layout 1 = bf16 MFMA, 0 = fp64 MFMA)
+//   shift_coef : > 0 = shifted Cholesky (Fukaya et al., "Shifted Cholesky QR for computing the QR factorization of ill-conditioned
+//                matrices", SIAM J. Sci. Comput. 2020): G + s I with s = shift_coef * trace(G) >= 11 (mn + n(n+1)) u ||A||_2^2 is
+//                safely positive definite for any fp32 input; the caller runs a second (unshifted) sweep on the resulting Q
+//   min_diag   : (bf16-split level) a column whose squared norm is so small that its fp32 products live near the denormal range was
+//                not accumulated accurately (measured: entries ~1e-22 gave ||Q^T Q - I|| = 1e-2) -> rejected, the fp64 level is exact
+//   status[0]  : 0 ok, 1 rejected: a pivot fell below min_ratio of its diagonal entry (2^-40 for the fp64 Gram matrix: cond(A)^2 is
+//                beyond fp64 Cholesky; 2^-5 for the bf16-split Gram matrix) or S exceeds max_scond (bf16-split Gram matrix only: its
+//                fp32 accumulation is good enough for nearly orthogonal columns only)
+//   status[1]  : bit pattern of the smallest pivot ratio (float), status[2]: of S (float), the scaled conditioning
+//                S = || D inverse(R) ||_F^2 / n with D = diag(sqrt(g_jj)): 1 for orthogonal columns of any scaling, ~cond^2 of the
+//                column-scaled matrix otherwise (an entry-wise error eps sqrt(g_ii g_jj) of G perturbs Q^T Q by <= eps n S)
+//   host_status: optional device-visible alias of pinned host memory that receives the three status words as well.  No fence: the
+//                host reads them only after the completion word of a LATER kernel on the stream, or after a stream synchronisation
+//                (a system-scope release here wrote back the whole L2 on the critical path of every call)
+//   gs_out     : receives the address of the fp64 LDS image of Z (chol_wide_kernel goes on with it)
 // ---------------------------------------------------------------------------------------------
 template <class LOADG>
 __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
@@ -1106,7 +1063,7 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 #ifdef TSQR_CHOL_STAMPS
 	if ((threadIdx.x & 63) == 0 && w < 4) chol_stamp_lds[w * CHOL_NSTAMP + 5] = __builtin_amdgcn_s_memrealtime();
 #endif
-	// the first four waves assemble G exactly as chol_body does (one value per thread and tile); the others wait at the barriers
+	// the first four waves assemble G (one value per thread and tile, loads first); the others wait at the barriers
 	double gv[10];
 	if (t < 256) {
 		int idx = 0;
@@ -1130,7 +1087,10 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 					const int row = 16 * ti + (f32_layout ? 4 * (l >> 4) + reg : (l >> 4) + 4 * reg);
 					const int col = 16 * tj + (l & 15);
 					const double v = gv[ti * 4 + tj - (ti * (ti + 1)) / 2];
-					if (row <= col) {                    // (upper-triangle owner writes both mirror positions: see chol_body)
+					// C/D layouts: f64 MFMA row = (lane>>4) + 4*reg, f32/bf16 MFMA row = 4*(lane>>4) + reg; col = lane&15.  A diagonal
+					// tile holds (i,j) and (j,i); in the bf16-split Gram matrix they can differ by an ulp (cross terms are added in
+					// opposite order), so only the upper-triangle owner writes both mirror positions
+					if (row <= col) {
 						Gs[row * 65 + col] = v;
 						Gs[col * 65 + row] = v;
 					}
@@ -1242,7 +1202,7 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 		CHOL_STAMP16(8 + 8 * gi + 3);
 	}
 	CHOL_STAMP16(2);
-	// scaled conditioning S and the status words, as in chol_body
+	// scaled conditioning S and the status words
 	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
 	if (j == 0) sred[w] = s_acc;
 	__syncthreads();
@@ -1294,33 +1254,8 @@ struct CholArgs {
 	float scond_floor;                   // bf16 level: S <= min(128, max(scond_floor, 0.12 sqrt(rows)))
 };
 
-__global__ __launch_bounds__(256) void chol_kernel(const CholArgs a) {
-	// prev_status: status word of an earlier factorisation this one depends on (speculatively enqueued second sweep): when that one
-	// was rejected this one reports "rejected" at once, so that everything enqueued behind it skips as well
-	if (a.prev_status && a.prev_status[0] != 0) {
-		if (threadIdx.x == 0) {
-			a.status[0] = 1u; a.status[1] = 0u; a.status[2] = 0u;
-			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
-		}
-		return;
-	}
-	const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
-	float min_ratio = 0.0f, max_scond = INFINITY;
-	double min_diag = 0.0, shift = 0.0;
-	if (a.level == 2) {
-		min_ratio = 0.03125f;
-		max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
-		min_diag = rows * 0x1p-90;
-	} else if (a.level == 1) {
-		min_ratio = 9.094947017729282e-13f;              // 2^-40
-	} else {
-		shift = a.shift_coef * (rows * (double)a.n + (double)a.n * (double)(a.n + 1));
-	}
-	chol_body(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
-	          shift, min_diag);
-}
-
-// the 64-column path's launch: sixteen waves (chol_body16)
+// the 64-column path's launch of the step.  prev_status: status word of an earlier factorisation this one depends on (speculatively
+// enqueued second sweep): when that one was rejected this one reports "rejected" at once, so that everything enqueued behind it skips as well
 __global__ __launch_bounds__(1024) void chol16_kernel(const CholArgs a) {
 	if (a.prev_status && a.prev_status[0] != 0) {
 		if (threadIdx.x == 0) {
@@ -1456,7 +1391,7 @@ __global__ __launch_bounds__(256) void cross_finish_kernel(float* __restrict__ r
 // ---------------------------------------------------------------------------------------------
 // trinv_kernel: Z = inverse of the n x n upper-triangular R (fp64 arithmetic, fp32 in/out), written zero-padded to
 // NP x NP column-major (ld NP).  Forward elimination of [R^T | I] with the rows interleaved over the four waves in
-// registers (same scheme as chol_kernel: M = R^-T, Z = M^T), one barrier per step.
+// registers (same scheme as chol_body16: M = R^-T, Z = M^T), one barrier per step.
 // ---------------------------------------------------------------------------------------------
 template <int U>
 __device__ __forceinline__ void trinv_group(double (&mm)[16], double* Mrow, const double* Rs, const double* rdiag,

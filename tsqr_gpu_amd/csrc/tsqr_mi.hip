@@ -50,7 +50,6 @@ struct Settings {
 	// conditioning S, and a diagnostic print of every Cholesky verdict
 	const float bf16_scond_floor = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);
 	const int debug = env_int("TSQR_MI_DEBUG", 0);
-	const int chol16 = env_int("TSQR_MI_CHOL16", 1);             // (A/B of the round: the Cholesky step on sixteen waves)
 };
 Settings g_set;
 std::atomic<unsigned> g_seq{0};                        // sequence numbers of the completion flags (any thread)
@@ -465,6 +464,17 @@ int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16) {
 	if (bf16 && c.gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		c.gramq_ready = false;
 		nparts = c.gramq_nparts;
+	} else if (bf16 && n == 64 && m % 128 == 0 && ld % 4 == 0 && ld <= ((size_t)1 << 24) && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+		// full 64-column matrices: block-pattern loads + LDS staging (gram_blk_kernel); everything else: gram_bf16_kernel
+		static DevOnce attr;
+		if (attr.need(c.dev)) {
+			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES));
+			attr.done(c.dev);
+		}
+		a.nchunks = (int)(m / 128);
+		nparts = std::min(a.nchunks, g.nblocks);
+		ProfScope ps(KC_GRAM, c.st);
+		hipLaunchKernelGGL(tsqrmi::gram_blk_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, a);
 	} else {
 		ProfScope ps(KC_GRAM, c.st);
 		switch (NT) {
@@ -505,8 +515,7 @@ int chol_from_g(Ctx& c, float* r, size_t ldr, size_t n, int level) {
 	a.n = (int)n; a.NT = NT; a.level = level; a.scond_floor = g_set.bf16_scond_floor;
 	{
 		ProfScope ps(KC_CHOL, c.st);
-		if (g_set.chol16) hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, a);
-		else hipLaunchKernelGGL(tsqrmi::chol_kernel, dim3(1), dim3(256), 0, c.st, a);
+		hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, a);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -856,7 +865,7 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 	float scond1 = 0.0f;                                 // scaled conditioning S reported by the accepted first sweep (single panel)
 
 	// R-factor engine levels: 2 bf16-split Gram (memory-bound), 1 fp64 Gram, 0 Householder TSQR.  Deferred mode runs a level
-	// speculatively and steps down when chol_kernel rejected it; with check_now panel_qr escalates per panel by itself.
+	// speculatively and steps down when chol16_kernel rejected it; with check_now panel_qr escalates per panel by itself.
 	const int first_level = !use_gram ? 0 : c.gram_level;
 	bool wide_done = false;
 	if (c.wide && n > PW && n <= 2 * PW && may_fall_back && first_level == 2 && !c.comm.active()) {

@@ -22,7 +22,7 @@ struct GramWideArgs {
 };
 
 // destination tile of the pair (ti, tj), ti <= tj, in the summed array: [G11: 10 tiles, NT = 4 order][G22: 10 tiles][G12: 16 tiles row-major]
-// -- the two diagonal blocks are then directly chol_kernel inputs
+// -- the first diagonal block is then directly a chol_body16 input
 __host__ __device__ constexpr int tri4(int ti, int tj) { return ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti); }
 __host__ __device__ constexpr int wide_tile(int ti, int tj) {
 	return (tj < 4) ? tri4(ti, tj) : ((ti >= 4) ? 10 + tri4(ti - 4, tj - 4) : 20 + ti * 4 + (tj - 4));
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
 struct PtrLoad { const double* p; __device__ double operator()(int e) const { return p[e]; } };
 struct CholWideArgs {
 	const double* gsum;                  // [G11 | G22 | G12] summed tiles (+ the row count behind them)
-	double* g2;                          // scratch: G22' in chol_body's tile order (2560 doubles)
+	double* g2;                          // (unused since round 3: G22' goes to the second factorisation through LDS)
 	float* r; size_t ldr; int n;         // R out (n x n)
-	float* zf1; float* zf2;              // fp32 Z11 / Z22 scratch (4096 floats each; chol_body writes them)
+	float* zf1; float* zf2;              // fp32 Z11 / Z22 scratch (4096 floats each; chol_body16 writes them)
 	float* zw;                           // 128 x 128 Z out
 	unsigned* st1; unsigned* st2;        // verdict words of the two blocks (diagnostics)
 	unsigned* status; unsigned* host_status;
