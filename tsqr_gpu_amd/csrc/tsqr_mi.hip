@@ -795,7 +795,7 @@ int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, c
 	unsigned* st1 = c.status_dev(2); unsigned* st2 = c.status_dev(3);
 	// full 64-row blocks of a 128-column matrix go to the fast form of the Gram kernel, whatever is left (ragged last rows, or the
 	// whole matrix when n < 128) to the general form; both write per-workgroup partials, one after the other
-	const size_t nfull = (n == 2 * PW) ? m / 64 : 0, nrest = cdiv(m, 64) - nfull;
+	const size_t nfull = (n == 2 * PW && lda <= ((size_t)1 << 23)) ? m / 64 : 0, nrest = cdiv(m, 64) - nfull;   // (fast form: 32-bit buffer offsets)
 	const int wgs_fast = (int)std::min<size_t>(nfull, WIDE_MAX_WGS), wgs_rest = (int)std::min<size_t>(nrest, WIDE_MAX_WGS);
 	const int wgs = wgs_fast + wgs_rest;
 	{

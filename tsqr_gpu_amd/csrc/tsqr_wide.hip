@@ -112,7 +112,7 @@ __device__ __forceinline__ void gram_wide_step(f32x4 (&acc)[9], const unsigned* 
 // (a move waits for the loads still in flight), and the loads of a full block are unconditional and back to back (a join between
 // them makes the compiler wait for each load before it issues the next).  Measured at 2^20 x 128 (537 MB, beyond the Infinity
 // Cache): 137 us = 3.9 TB/s; the loads alone take 130 us in this geometry.
-// FAST: every block is full (64 rows inside the matrix, n == 128).  !FAST: the general form (ragged rows, n < 128), one block in
+// FAST: every block is full (64 rows inside the matrix, n == 128, 128 lda floats < 4 GiB).  !FAST: the general form (ragged rows, n < 128), one block in
 // flight -- the host sends only what FAST cannot take there.
 constexpr int GW_LDS_BYTES = 2 * 3 * 128 * GW_CS * 4;
 template <bool FAST>
@@ -128,13 +128,17 @@ __global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
 	f64x4 tot[9];
 #pragma unroll
 	for (int t = 0; t < 9; t++) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[t] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+	// FAST: buffer loads -- descriptor on the block (wave-uniform), one loop-invariant 32-bit per-thread offset, the column group in the
+	// scalar offset.  (With flat loads the allocator recycled registers of the set in flight for the 64-bit addresses and the wait it
+	// then needs drained the queue at every second block: s_waitcnt vmcnt(0) at the loop head; see gram_blk_kernel.)
+	const unsigned voff = (unsigned)(((size_t)lcol * a.lda + lrow) * sizeof(float));
+	const unsigned soff0 = (unsigned)((size_t)(4 * wv) * a.lda * sizeof(float)), soffk = (unsigned)(32 * a.lda * sizeof(float));
 	auto load_block = [&](f32x4 (&v)[4], int b) {
 		if constexpr (FAST) {
 			// (no branch at all: past the end the last block is simply loaded again and never used)
-			const size_t row = (size_t)(a.blk0 + min(b, a.nblk - 1)) * 64 + lrow;
-			const float* src = a.a + (size_t)(4 * wv + lcol) * a.lda + row;
+			const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a + (size_t)(a.blk0 + min(b, a.nblk - 1)) * 64), 0, -1, 0x00020000);
 #pragma unroll
-			for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const f32x4u*>(src + (size_t)(32 * k) * a.lda);
+			for (int k = 0; k < 4; k++) v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff0 + k * soffk, 0));
 		} else {
 			const size_t row = (size_t)(a.blk0 + b) * 64 + lrow;
 #pragma unroll
