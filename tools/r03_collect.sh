@@ -22,7 +22,7 @@ tools/gpu_timeline.sh r03_c3_notc -- 200 1048576 128 fp32_notc
 tools/gpu_timeline.sh r03_reorth -- 200 1048576 64 fp32_tc_cor 1
 tools/gpu_timeline.sh r03_policy1_tc_cor -- 100 1048576 64 fp32_tc_cor 0 1
 tools/gpu_timeline.sh r03_policy1_notc -- 100 1048576 64 fp32_notc 0 1
-tools/gpu_timeline.sh r03_2p23 -- 60 8388608 64 fp32_tc_cor
+tools/gpu_timeline.sh r03_2p23 -- 120 8388608 64 fp32_tc_cor
 
 step "HBM traffic of the headline kernels (two --pmc passes)"
 for cnt in FETCH_SIZE WRITE_SIZE; do

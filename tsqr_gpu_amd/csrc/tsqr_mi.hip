@@ -464,8 +464,11 @@ int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16) {
 	if (bf16 && c.gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		c.gramq_ready = false;
 		nparts = c.gramq_nparts;
-	} else if (bf16 && n == 64 && m % 128 == 0 && ld % 4 == 0 && ld <= ((size_t)1 << 24) && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-		// full 64-column matrices: block-pattern loads + LDS staging (gram_blk_kernel); everything else: gram_bf16_kernel
+	} else if (bf16 && n == 64 && m % 128 == 0 && m <= ((size_t)1 << 20) && ld % 4 == 0 && ld <= ((size_t)1 << 24) && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+		// full 64-column matrices that fit the 256 MiB Infinity Cache: block-pattern loads + LDS staging (gram_blk_kernel); everything
+		// else: gram_bf16_kernel.  (Measured, kernel / call period under the profiler: 2^21 rows 93.8 / 322.6 vs 95.8 / 319.4 us,
+		// 2^22 rows 190.0 / 621.2 vs 192.0 / 621.0, 2^23 rows 421 / 1310 vs 381 / 1266 -- beyond the cache the chunk kernel is as good
+		// or better; at 2^20 rows the call is 3-5 us faster with the block kernel, profiles/r03_experiment_log.md.)
 		static DevOnce attr;
 		if (attr.need(c.dev)) {
 			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES));
