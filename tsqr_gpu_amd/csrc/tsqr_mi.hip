@@ -174,10 +174,9 @@ GramPlan gram_plan(size_t m, size_t n) {
 }
 
 // extra work space of the one-panel path for 64 < n <= 128 (offsets in floats from WqLayout::wide; the doubles first, 16-byte aligned):
-// [summed tiles 36*256 + row count (+pad)][G22' 10*256] | [Z 128 x 128 fp32][Z22 fp32 4096]
+// [summed tiles 36*256 + row count (+pad)] | [Z 128 x 128 fp32][Z22 fp32 4096]
 constexpr size_t WIDE_G_DOUBLES = 36 * 256 + 8;
-constexpr size_t WIDE_OFF_G2 = 2 * WIDE_G_DOUBLES, WIDE_OFF_ZW = WIDE_OFF_G2 + 2 * 2560, WIDE_OFF_ZF2 = WIDE_OFF_ZW + 128 * 128,
-                 WIDE_FLOATS = WIDE_OFF_ZF2 + 4096;
+constexpr size_t WIDE_OFF_ZW = 2 * WIDE_G_DOUBLES, WIDE_OFF_ZF2 = WIDE_OFF_ZW + 128 * 128, WIDE_FLOATS = WIDE_OFF_ZF2 + 4096;
 constexpr int WIDE_MAX_WGS = 256;                       // gram_wide_kernel: one eight-wave workgroup per CU
 inline size_t wide_part_floats(size_t m) { return (std::min<size_t>((m + 63) / 64, WIDE_MAX_WGS) + 1) * 36 * 256 * 2; }
 
@@ -614,6 +613,10 @@ int engine_of(int mode) {
 
 // r <- r2 * r1 (upper triangular n x n, fp64 accumulation; r may not alias r1 / r2)
 void launch_rmul(float* r, size_t ldr, const float* r2, size_t ldr2, const float* r1, size_t ldr1, size_t n, hipStream_t st) {
+	if (n <= 64) {
+		hipLaunchKernelGGL(tsqrmi::rmul64_kernel, dim3(1), dim3(1024), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
+		return;
+	}
 	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
 	hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
 }
@@ -713,8 +716,7 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 				}
 			}
 			if (rc) return rc;
-			const unsigned gbp = (unsigned)std::min<size_t>(1024, cdiv(cc * cc, 256));
-			hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gbp), dim3(256), 0, c.st, rpp, ldr, r2, cc, r1, cc, (int)cc);
+			launch_rmul(rpp, ldr, r2, cc, r1, cc, cc, c.st);
 			HIPCHK(hipGetLastError());
 			c.min_level = 0;
 			c.used_shift = true;
@@ -792,7 +794,6 @@ template <int E> int launch_apply_wide(Ctx& c, tsqrmi::ApplyArgs a) {
 int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, const float* a, size_t lda, size_t m, size_t n) {
 	float* w = c.wq + c.L.wide;
 	double* gsum = reinterpret_cast<double*>(w);
-	double* g2 = reinterpret_cast<double*>(w + WIDE_OFF_G2);
 	float* zw = w + WIDE_OFF_ZW;
 	float* zf2 = w + WIDE_OFF_ZF2;
 	unsigned* st1 = c.status_dev(2); unsigned* st2 = c.status_dev(3);
@@ -827,7 +828,7 @@ int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, c
 		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, gsum, reinterpret_cast<const double*>(c.wr), wgs, nelem, (double)m);
 		// chol(G11) -> Schur complement -> chol(G22') -> Z12 + verdict: one workgroup, one launch (chol_wide_kernel)
 		tsqrmi::CholWideArgs wa{};
-		wa.gsum = gsum; wa.g2 = g2; wa.r = r; wa.ldr = ldr; wa.n = (int)n; wa.zf1 = c.wq + c.L.z; wa.zf2 = zf2; wa.zw = zw;
+		wa.gsum = gsum; wa.r = r; wa.ldr = ldr; wa.n = (int)n; wa.zf1 = c.wq + c.L.z; wa.zf2 = zf2; wa.zw = zw;
 		wa.st1 = st1; wa.st2 = st2; wa.status = c.status_dev(c.slot);
 		wa.host_status = c.hsig.dev ? c.hsig.dev + 4 * c.slot : nullptr;
 		wa.prev_status = c.prev_slot >= 0 ? c.status_dev(c.prev_slot) : nullptr;

@@ -248,7 +248,6 @@ __global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
 struct PtrLoad { const double* p; __device__ double operator()(int e) const { return p[e]; } };
 struct CholWideArgs {
 	const double* gsum;                  // [G11 | G22 | G12] summed tiles (+ the row count behind them)
-	double* g2;                          // (unused since round 3: G22' goes to the second factorisation through LDS)
 	float* r; size_t ldr; int n;         // R out (n x n)
 	float* zf1; float* zf2;              // fp32 Z11 / Z22 scratch (4096 floats each; chol_body16 writes them)
 	float* zw;                           // 128 x 128 Z out
