@@ -6,6 +6,7 @@ mkdir -p gpurun_out
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/verify_pytest.log 2>&1; rc=$?
 tail -4 gpurun_out/verify_pytest.log
 [ $rc -ne 0 ] && exit $rc
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 || exit 1
 run() { n=$1; shift; timeout -k 10 400 python bench.py "$@" > gpurun_out/verify_bench_$n.json 2> gpurun_out/verify_bench_$n.err || { echo "bench $n failed"; tail -5 gpurun_out/verify_bench_$n.err; exit 1; }
 	python - gpurun_out/verify_bench_$n.json $n <<'PY'
 import json, sys
