@@ -23,11 +23,10 @@ s = out.cpu().numpy().reshape(4, 160)
 clk = (s[0, 3] - s[0, 0]) / max(1, (s[0, 4] - s[0, 5])) * 100.0      # MHz: shader cycles per 100 MHz tick
 print("chol16_kernel n=%d: kernel body %d cycles (wave 0), clock ~%.0f MHz => %.2f us" % (n, s[0, 3] - s[0, 0], clk, (s[0, 3] - s[0, 0]) / clk))
 print("prologue (start -> first group) %d   elimination %d   epilogue (verdict, images out) %d" % (s[0, 1] - s[0, 0], s[0, 2] - s[0, 1], s[0, 3] - s[0, 2]))
-print("group: owner section | barrier wait of the owner / of another wave | updates after the barrier (owner / another wave) | period")
+print("group (the stamp table keeps waves 0-3, i.e. the owners of groups 0-3): barrier wait of the owner / of wave (g + 2) % 4 | work after the barrier, owner / that wave | period (wave 0)")
 for gi in range(min(4, (n + 3) // 4)):
-    U = gi % 4; oth = (U + 2) % 4
+    oth = (gi + 2) % 4
     b = 8 + 8 * gi
-    o, x = s[U], s[oth]
-    print("g%02d owner w%d: %5d | bar %5d %5d | upd %5d %5d | period %5d" % (
-        gi, U, o[b + 1] - o[b], o[b + 2] - o[b + 1], x[b + 2] - x[b + 1], o[b + 3] - o[b + 2], x[b + 3] - x[b + 2],
-        (o[b + 8] - o[b]) if gi + 1 < (n + 3) // 4 else 0))
+    o, x, w0 = s[gi], s[oth], s[0]
+    print("g%02d owner w%d: bar %5d %5d | after %5d %5d | period %5d" % (
+        gi, gi, o[b + 2] - o[b + 1], x[b + 2] - x[b + 1], o[b + 3] - o[b + 2], x[b + 3] - x[b + 2], w0[b + 9] - w0[b + 1]))
