@@ -44,22 +44,48 @@ const state_t error_unsupported_mode = 2;      // new: compute_mode without a gf
 
 using handle_t = hipStream_t;                  // takes the place of cublasHandle_t (see the header comment)
 
-// Element types.  Only the fp32 I/O modes are implemented on gfx950; their io / working types are float,
-// as in reference src/tsqr.hpp:25-39 (the half-typed modes are declared so that code naming them still
-// compiles; calling them returns error_unsupported_mode).
+// Element types, as in reference src/tsqr.hpp:25-39 for the io type: float for the fp32 modes, IEEE binary16 (the reference's
+// `half`) for fp16_notc / fp16_tc_nocor.  The WORKING types are float for every mode (the reference's are half for the fp16 modes
+// and for the working Q of fp32_tc_nocor): this engine factors in fp32 and converts at the boundary.  The remaining modes are
+// declared so that code naming them still compiles; calling them returns error_unsupported_mode.
+using half_t = mtk::tsqr::half_t;
 template <mtk::qr::compute_mode mode> struct get_working_q_type { using type = float; };
 template <mtk::qr::compute_mode mode> struct get_working_r_type { using type = float; };
 template <mtk::qr::compute_mode mode> struct get_io_type { using type = float; };
+template <> struct get_io_type<fp16_notc> { using type = half_t; };
+template <> struct get_io_type<fp16_tc_nocor> { using type = half_t; };
 
 // get working memory size (element counts), reference src/blockqr.hpp:55-57
 inline std::size_t get_working_q_size(const std::size_t m, const std::size_t n) { return tsqr_mi_working_q_size(m, n); }
 inline std::size_t get_working_r_size(const std::size_t m, const std::size_t n) { return tsqr_mi_working_r_size(m, n); }
 inline std::size_t get_working_l_size(const std::size_t m) { return tsqr_mi_working_l_size(m); }
+// the same per mode: the fp16 I/O modes need room for the widened A, Q and R on top (what buffer<mode>::allocate uses; a caller
+// that allocates by hand for an fp16 mode must use these, in elements of get_working_{q,r}_type<mode>::type = float)
+template <mtk::qr::compute_mode mode> inline std::size_t get_working_q_size(const std::size_t m, const std::size_t n) {
+	return (mode == fp16_notc || mode == fp16_tc_nocor) ? tsqr_mi_working_q_size_f16(m, n) : tsqr_mi_working_q_size(m, n);
+}
+template <mtk::qr::compute_mode mode> inline std::size_t get_working_r_size(const std::size_t m, const std::size_t n) {
+	return (mode == fp16_notc || mode == fp16_tc_nocor) ? tsqr_mi_working_r_size_f16(m, n) : tsqr_mi_working_r_size(m, n);
+}
 
 namespace detail {
 inline void check(hipError_t e, const char* what) {
 	if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
+// the C entry point of an io type
+template <class IO> struct entry;
+template <> struct entry<float> {
+	static int call(int mode, int reorth, float* q, std::size_t ldq, float* r, std::size_t ldr, float* a, std::size_t lda, std::size_t m, std::size_t n,
+	                void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl, hipStream_t stream) {
+		return tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq, wr, reorth_w, d_wl, h_wl, stream);
+	}
+};
+template <> struct entry<half_t> {
+	static int call(int mode, int reorth, half_t* q, std::size_t ldq, half_t* r, std::size_t ldr, half_t* a, std::size_t lda, std::size_t m, std::size_t n,
+	                void* wq, void* wr, half_t* reorth_w, unsigned* d_wl, unsigned* h_wl, hipStream_t stream) {
+		return tsqr_mi_qr_f16(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq, wr, reorth_w, d_wl, h_wl, stream);
+	}
+};
 }  // namespace detail
 
 template <mtk::qr::compute_mode mode, bool Reorthogonalize>
@@ -81,8 +107,8 @@ struct buffer {
 		if (dwq != nullptr || dwr != nullptr || dl != nullptr || hl != nullptr) {
 			throw std::runtime_error("The buffer has been already allocated");
 		}
-		const auto wq_size = sizeof(typename get_working_q_type<mode>::type) * get_working_q_size(m, n);
-		const auto wr_size = sizeof(typename get_working_r_type<mode>::type) * get_working_r_size(m, n);
+		const auto wq_size = sizeof(typename get_working_q_type<mode>::type) * get_working_q_size<mode>(m, n);
+		const auto wr_size = sizeof(typename get_working_r_type<mode>::type) * get_working_r_size<mode>(m, n);
 		const auto l_size = sizeof(unsigned) * get_working_l_size(m);
 		detail::check(hipMalloc(reinterpret_cast<void**>(&dwq), wq_size), "hipMalloc(dwq)");
 		detail::check(hipMalloc(reinterpret_cast<void**>(&dwr), wr_size), "hipMalloc(dwr)");
@@ -114,8 +140,8 @@ struct buffer {
 		if (dwq != nullptr || dwr != nullptr || dl != nullptr || hl != nullptr) {
 			throw std::runtime_error("The buffer has been already allocated");
 		}
-		const auto wq_size = sizeof(typename get_working_q_type<mode>::type) * get_working_q_size(m, n);
-		const auto wr_size = sizeof(typename get_working_r_type<mode>::type) * get_working_r_size(m, n);
+		const auto wq_size = sizeof(typename get_working_q_type<mode>::type) * get_working_q_size<mode>(m, n);
+		const auto wr_size = sizeof(typename get_working_r_type<mode>::type) * get_working_r_size<mode>(m, n);
 		const auto l_size = sizeof(unsigned) * get_working_l_size(m);
 		detail::check(hipHostMalloc(reinterpret_cast<void**>(&dwq), wq_size), "hipHostMalloc(dwq)");
 		detail::check(hipHostMalloc(reinterpret_cast<void**>(&dwr), wr_size), "hipHostMalloc(dwr)");
@@ -159,7 +185,7 @@ inline state_t qr(
 		unsigned* const d_wl_ptr,
 		unsigned* const h_wl_ptr,
 		handle_t const stream = nullptr) {
-	const int st = tsqr_mi_qr_f32(static_cast<int>(mode), Reorthogonalize ? 1 : 0,
+	const int st = detail::entry<typename mtk::qr::get_io_type<mode>::type>::call(static_cast<int>(mode), Reorthogonalize ? 1 : 0,
 	                              q_ptr, ldq, r_ptr, ldr, a_ptr, lda, m, n,
 	                              wq_ptr, wr_ptr, reorth_r_ptr, d_wl_ptr, h_wl_ptr, stream);
 	if (st < 0) throw std::runtime_error(std::string("mtk::qr::qr: ") + tsqr_mi_last_error());

@@ -4,8 +4,8 @@
 // reference; this engine takes any n <= 64 through the same entry.
 //
 // Header-only over the extern "C" ABI of libtsqr_mi.so.  The stream argument is a hipStream_t where the reference has a
-// cudaStream_t.  fp32 I/O modes only (fp32_notc, fp32_tc_cor, fp32_tc_nocor); the others throw std::runtime_error -- tsqr16 returns
-// void in the reference, so there is no status to report them through.
+// cudaStream_t.  fp32_notc, fp32_tc_cor, fp32_tc_nocor (float I/O) and fp16_notc, fp16_tc_nocor (half I/O); the others throw
+// std::runtime_error -- tsqr16 returns void in the reference, so there is no status to report them through.
 #ifndef __TSQR_HPP__
 #define __TSQR_HPP__
 #include <hip/hip_runtime.h>
@@ -33,20 +33,42 @@ enum compute_mode {
 inline std::size_t get_batch_size_log2(const std::size_t m) { return tsqr_mi_batch_size_log2(m); }
 inline std::size_t get_batch_size(const std::size_t m) { return tsqr_mi_batch_size(m); }
 
-// every mode this engine implements works on float; the half-typed modes keep their names so that code mentioning them compiles.
-// One difference a hand-allocating caller must know: the reference's working Q of fp32_tc_nocor is `half` (reference
-// src/tsqr.hpp:29), here it is float like every other buffer -- size the work space in ELEMENTS of these traits' types
-// (get_working_q_size(m, n) * sizeof(get_working_q_type<mode>::type), as mtk::tsqr::buffer and mtk::qr::buffer do), never in
-// elements of the reference's type: a `half`-sized wq would be half the bytes this engine writes.
+// io type as in reference src/tsqr.hpp:36-39: float for the fp32 modes, IEEE binary16 (the reference's `half`) for fp16_notc /
+// fp16_tc_nocor.  The WORKING types are float for every mode this engine implements (it factors in fp32 and converts at the
+// boundary), the other modes keep their names so that code mentioning them compiles.
+// One difference a hand-allocating caller must know: the reference's working types are `half` for the fp16 modes and for the
+// working Q of fp32_tc_nocor (reference src/tsqr.hpp:27-34), here they are float -- size the work space in ELEMENTS of these traits'
+// types (get_working_q_size<mode>(m, n) * sizeof(get_working_q_type<mode>::type), as mtk::tsqr::buffer and mtk::qr::buffer do),
+// never in elements of the reference's type: a `half`-sized wq would be half the bytes this engine writes.
+using half_t = _Float16;
 template <compute_mode mode> struct get_working_q_type { using type = float; };
 template <compute_mode mode> struct get_working_r_type { using type = float; };
 template <compute_mode mode> struct get_io_type { using type = float; };
+template <> struct get_io_type<fp16_notc> { using type = half_t; };
+template <> struct get_io_type<fp16_tc_nocor> { using type = half_t; };
 
 inline std::size_t get_working_q_size(const std::size_t m, const std::size_t n) { return tsqr_mi_working_q_size(m, n); }
 inline std::size_t get_working_r_size(const std::size_t m, const std::size_t n) { return tsqr_mi_working_r_size(m, n); }
 inline std::size_t get_working_l_size(const std::size_t m) { return tsqr_mi_working_l_size(m); }
+// per mode: the fp16 I/O modes need room for the widened A, Q and R on top
+template <compute_mode mode> inline std::size_t get_working_q_size(const std::size_t m, const std::size_t n) {
+	return (mode == fp16_notc || mode == fp16_tc_nocor) ? tsqr_mi_working_q_size_f16(m, n) : tsqr_mi_working_q_size(m, n);
+}
+template <compute_mode mode> inline std::size_t get_working_r_size(const std::size_t m, const std::size_t n) {
+	return (mode == fp16_notc || mode == fp16_tc_nocor) ? tsqr_mi_working_r_size_f16(m, n) : tsqr_mi_working_r_size(m, n);
+}
 
 namespace detail {
+// the C entry point of an io type (reorth = 0: one panel)
+inline int panel_entry(int mode, float* q, std::size_t ldq, float* r, std::size_t ldr, const float* a, std::size_t lda, std::size_t m, std::size_t n,
+                       void* wq, void* wr, unsigned* d_wl, unsigned* h_wl, hipStream_t stream) {
+	// (a panel of at most 64 columns is never written to by the engine: the const_cast only matches the C signature)
+	return tsqr_mi_qr_f32(mode, 0, q, ldq, r, ldr, const_cast<float*>(a), lda, m, n, wq, wr, nullptr, d_wl, h_wl, stream);
+}
+inline int panel_entry(int mode, half_t* q, std::size_t ldq, half_t* r, std::size_t ldr, const half_t* a, std::size_t lda, std::size_t m, std::size_t n,
+                       void* wq, void* wr, unsigned* d_wl, unsigned* h_wl, hipStream_t stream) {
+	return tsqr_mi_qr_f16(mode, 0, q, ldq, r, ldr, a, lda, m, n, wq, wr, nullptr, d_wl, h_wl, stream);
+}
 enum class where { device, pinned_host };
 inline void* grab(where w, std::size_t bytes, const char* what) {
 	void* p = nullptr;
@@ -83,7 +105,7 @@ struct buffer {
 private:
 	void fill(detail::where w, const std::size_t m, const std::size_t n) {
 		if (dwq || dwr || dl || hl) throw std::runtime_error("The buffer has been already allocated");
-		const std::size_t q_bytes = sizeof(*dwq) * get_working_q_size(m, n), r_bytes = sizeof(*dwr) * get_working_r_size(m, n),
+		const std::size_t q_bytes = sizeof(*dwq) * get_working_q_size<mode>(m, n), r_bytes = sizeof(*dwr) * get_working_r_size<mode>(m, n),
 		                  l_bytes = sizeof(unsigned) * get_working_l_size(m);
 		dwq = static_cast<decltype(dwq)>(detail::grab(w, q_bytes, "mtk::tsqr::buffer dwq"));
 		dwr = static_cast<decltype(dwr)>(detail::grab(w, r_bytes, "mtk::tsqr::buffer dwr"));
@@ -112,9 +134,8 @@ inline void tsqr16(
 		unsigned* const h_working_l_ptr,
 		hipStream_t const stream = nullptr) {
 	if (n > 64) throw std::runtime_error("mtk::tsqr::tsqr16: one panel has at most 64 columns (the reference's limit is 16)");
-	// (a panel of at most 64 columns is never written to by the engine: the const_cast only matches the C signature)
-	const int st = tsqr_mi_qr_f32(static_cast<int>(mode), 0, q_ptr, ldq, r_ptr, ldr, const_cast<float*>(a_ptr), lda, m, n,
-	                              working_q_ptr, working_r_ptr, nullptr, d_working_l_ptr, h_working_l_ptr, stream);
+	const int st = detail::panel_entry(static_cast<int>(mode), q_ptr, ldq, r_ptr, ldr, a_ptr, lda, m, n,
+	                                   working_q_ptr, working_r_ptr, d_working_l_ptr, h_working_l_ptr, stream);
 	if (st < 0) throw std::runtime_error(std::string("mtk::tsqr::tsqr16: ") + tsqr_mi_last_error());
 	if (st != 0) throw std::runtime_error(st == 2 ? "mtk::tsqr::tsqr16: compute_mode not implemented on gfx950"
 	                                              : "mtk::tsqr::tsqr16: invalid matrix size");

@@ -115,6 +115,26 @@ def test_csv_drivers_schema_and_values(env):
     assert rows[0][3] < 5e-6 and rows[0][5] < 2e-6         # BCGS2 restores orthogonality at cond 1e4
 
 
+def test_csv_drivers_fp16_modes(env):
+    """the half-typed lines of the reference's sweep (src/main.cu:15-16, 38-39, 65-66: type column `half`)"""
+    torch, bq, harness, oracle = env
+    out = io.StringIO()
+    rows = harness.accuracy([(4096, 64, 1.0)], C=2, mode=bq.compute_mode.fp16_tc_nocor, reorth=False, out=out)
+    rows += harness.accuracy([(2000, 100, 1.0)], C=2, mode=bq.compute_mode.fp16_notc, reorth=True, out=out, head=False)
+    lines = out.getvalue().strip().split("\n")
+    assert lines[1].startswith("4096,64,1,half,fp16_tc_nocor,0,") and lines[2].startswith("2000,100,1,half,fp16_notc,1,")
+    for (_, n, rm, rv, om, ov) in rows:
+        assert rm < 1e-3 and om < 5e-3 / math.sqrt(n)       # the fp16 rounding of Q and R
+    out = io.StringIO()
+    harness.speed([(1 << 16, 64, 1.0)], C=4, mode=bq.compute_mode.fp16_tc_nocor, out=out)
+    f = out.getvalue().strip().split("\n")[1].split(",")
+    assert f[3] == "half" and f[4] == "fp16_tc_nocor" and float(f[6]) > 0 and int(f[8]) > 0
+    out = io.StringIO()
+    rows = harness.accuracy_cond([(4096, 64, 1e2)], C=2, mode=bq.compute_mode.fp16_notc, reorth=True, out=out)
+    assert out.getvalue().strip().split("\n")[1].startswith("4096,64,100,half,fp16_notc,1,")
+    assert rows[0][3] < 1e-3 and rows[0][5] < 5e-3 / 8
+
+
 def test_rocsolver_comparison_columns(env):
     """The vendor-library lines of the reference's sweep (src/test.cu:366-593, cuSOLVER there, rocSOLVER here)."""
     torch, bq, harness, oracle = env

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The reference's test driver (src/main.cu:13-121) on this engine: accuracy / speed / condition-number sweeps for the
-modes gfx950 implements (fp32_notc, fp32_tc_cor), with and without re-orthogonalisation, printing the reference's CSV
+modes gfx950 implements (fp16_notc, fp16_tc_nocor, fp32_notc, fp32_tc_nocor, fp32_tc_cor: the order of src/main.cu), with and without
+re-orthogonalisation, printing the reference's CSV
 schema so that its scripts/*/mk_*.py plotters read the output.  Defaults are reduced sweeps that finish in minutes;
 --full selects the reference's own lists (m = 2^10..2^15, n = 2^10..m; cond sweep at 2^15 x 2^7, c = 2^2..2^15)."""
 import argparse
@@ -20,7 +21,7 @@ def main():
     ap.add_argument("--what", default="accuracy,speed,cond")
     args = ap.parse_args()
     what = args.what.split(",")
-    modes = [bq.compute_mode.fp32_notc, bq.compute_mode.fp32_tc_nocor, bq.compute_mode.fp32_tc_cor]
+    modes = [bq.compute_mode.fp16_notc, bq.compute_mode.fp16_tc_nocor, bq.compute_mode.fp32_notc, bq.compute_mode.fp32_tc_nocor, bq.compute_mode.fp32_tc_cor]
     if args.full:
         C = args.count or 16
         sizes = [(1 << m, 1 << n, 1.0) for m in range(10, 16) for n in range(10, m + 1)]

@@ -31,8 +31,17 @@ for i, name in enumerate(shape):
         gl = "gap to the first kernel of the next call"
     tot += d + g
     out.append("%-52s %8.2f us   %s %6.2f us" % (name[:52], d, gl, g))
-per = st.median((calls[j + 1][0][0] - calls[j][0][0]) / 1e3 for j in range(len(calls) - 1))
+periods = [(calls[j + 1][0][0] - calls[j][0][0]) / 1e3 for j in range(len(calls) - 1)]
+per = st.median(periods)
 out.append("sum of medians %.2f us; median call period (start to start) %.2f us" % (tot, per))
+# outliers: calls whose period is more than twice the median -- where the time went (longest kernel, longest gap inside the call,
+# gap to the next call's first kernel)
+slow = [j for j, p in enumerate(periods) if p > 2 * per]
+out.append("calls with a period above twice the median: %d of %d" % (len(slow), len(periods)) + ("" if not slow else " -- " + "; ".join(
+    "call %d: %.0f us (longest kernel %s %.0f us, largest gap inside the call %.0f us, gap to the next call %.0f us)" % (
+        skip + j, periods[j], *max(((c[2], (c[1] - c[0]) / 1e3) for c in calls[j]), key=lambda t: t[1]),
+        max([(calls[j][i + 1][0] - calls[j][i][1]) / 1e3 for i in range(len(calls[j]) - 1)] or [0.0]),
+        (calls[j + 1][0][0] - calls[j][-1][1]) / 1e3) for j in slow[:6])))
 print("\n".join(out))
 if len(sys.argv) > 3:
     open(sys.argv[3], "w").write("\n".join(out) + "\n")

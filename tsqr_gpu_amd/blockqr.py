@@ -46,7 +46,9 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_gram_elems", "tsqr_mi_gram_f32", "tsqr_mi_chol_f32", "tsqr_mi_chol_status", "tsqr_mi_stream_wait", "tsqr_mi_apply_z_f32", "tsqr_mi_validate_f32",
     "tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist", "tsqr_mi_qr_f32_dist_cb",
     "tsqr_mi_qr_f32_loop", "tsqr_mi_qr_f32_dist_fn", "tsqr_mi_qr_f32_dist_fn_loop", "tsqr_mi_qr_f32_dist_cb_loop",
+    "tsqr_mi_qr_f16", "tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16",
 ]
+FP16_MODES = (compute_mode.fp16_notc, compute_mode.fp16_tc_nocor)     # io type half in the reference (src/tsqr.hpp:38-39)
 
 _lib = None
 
@@ -100,6 +102,11 @@ def lib():
     L.tsqr_mi_qr_f32_dist_cb.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, ci, vp]
     L.tsqr_mi_qr_f32_loop.restype = ci
     L.tsqr_mi_qr_f32_loop.argtypes = [ci] + L.tsqr_mi_qr_f32.argtypes
+    L.tsqr_mi_qr_f16.restype = ci
+    L.tsqr_mi_qr_f16.argtypes = L.tsqr_mi_qr_f32.argtypes
+    for name in ("tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16"):
+        getattr(L, name).restype = sz
+        getattr(L, name).argtypes = [sz, sz]
     L.tsqr_mi_qr_f32_dist_fn.restype = ci
     L.tsqr_mi_qr_f32_dist_fn.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, ci, vp]
     L.tsqr_mi_qr_f32_dist_fn_loop.restype = ci
@@ -173,6 +180,8 @@ class buffer:
         if self.dwq is not None or self.dwr is not None or self.dl is not None or self.hl is not None:
             raise RuntimeError("The buffer has been already allocated")
         wq, wr, wl = get_working_q_size(m, n), get_working_r_size(m, n), get_working_l_size(m)
+        if self.mode in FP16_MODES:                          # room for the widened A, Q and R of the fp16 entry (in 4-byte units)
+            wq, wr = lib().tsqr_mi_working_q_size_f16(m, n), lib().tsqr_mi_working_r_size_f16(m, n)
         self.dwq = torch.empty(max(wq, 1), dtype=torch.float32, device=self.device)
         self.dwr = torch.empty(max(wr, 1), dtype=torch.float32, device=self.device)
         self.dl = torch.empty(max(wl, 1), dtype=torch.int32, device=self.device)
@@ -194,7 +203,8 @@ def qr(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize
     """mtk::qr::qr<mode, Reorthogonalize>(q, ldq, r, ldr, a, lda, m, n, buffer, handle).
 
     q, r, a: float32 torch tensors on the GPU holding column-major data (any shape; only data_ptr is
-    used).  `stream` (torch.cuda.Stream or None = current) takes the place of the cublasHandle_t, whose
+    used) -- float16 tensors for the two fp16 I/O modes (io type half in the reference, src/tsqr.hpp:38-39; the buffer must have
+    been allocated for such a mode).  `stream` (torch.cuda.Stream or None = current) takes the place of the cublasHandle_t, whose
     only role in the reference is to carry the stream (src/blockqr.cu:58-59).  Blocking, returns state_t.
     Runtime failures raise RuntimeError (the reference throws std::runtime_error from CUTF_CHECK_ERROR).
     """
@@ -203,11 +213,19 @@ def qr(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize
     reorth = bf.reorthogonalize if reorthogonalize is None else bool(reorthogonalize)
     if stream is None:
         stream = torch.cuda.current_stream()
-    st = lib().tsqr_mi_qr_f32(int(mode), int(reorth), _ptr(q), ldq, _ptr(r), ldr, _ptr(a), lda, m, n,
-                              _ptr(bf.dwq), _ptr(bf.dwr), _ptr(bf.dw_reorth_r), _ptr(bf.dl), _ptr(bf.hl),
-                              stream.cuda_stream)
+    if mode in FP16_MODES:
+        for t in (q, r, a):
+            if t is not None and t.dtype != torch.float16:
+                raise TypeError("%s takes float16 tensors (io type half, reference src/tsqr.hpp:38-39)" % mode.name)
+        if bf.mode not in FP16_MODES:
+            raise RuntimeError("the buffer was allocated for %s: an fp16 mode needs the larger work space of its own allocate()" % bf.mode.name)
+        fn, name = lib().tsqr_mi_qr_f16, "tsqr_mi_qr_f16"
+    else:
+        fn, name = lib().tsqr_mi_qr_f32, "tsqr_mi_qr_f32"
+    st = fn(int(mode), int(reorth), _ptr(q), ldq, _ptr(r), ldr, _ptr(a), lda, m, n,
+            _ptr(bf.dwq), _ptr(bf.dwr), _ptr(bf.dw_reorth_r), _ptr(bf.dl), _ptr(bf.hl), stream.cuda_stream)
     if st < 0:
-        raise RuntimeError("tsqr_mi_qr_f32 failed: %s" % last_error())
+        raise RuntimeError("%s failed: %s" % (name, last_error()))
     return st
 
 

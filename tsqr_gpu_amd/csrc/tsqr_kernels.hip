@@ -1205,7 +1205,7 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 	// scaled conditioning S and the status words
 	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
 	if (j == 0) sred[w] = s_acc;
-	__syncthreads();
+	lds_barrier();                                       // (LDS only: the verdict arithmetic runs while the last rows' stores are acknowledged)
 	if (w == 0) {
 		const double d0 = dg[j], p0 = pv[j];
 		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
@@ -1959,6 +1959,44 @@ __global__ __launch_bounds__(1024) void rmul64_kernel(float* __restrict__ r, siz
 // so that the host can spin on the word instead of paying a stream synchronisation (stream order makes it a full barrier).
 __global__ void host_flag_kernel(unsigned* __restrict__ host_flag, unsigned seq) {
 	*reinterpret_cast<volatile unsigned*>(host_flag) = seq;
+}
+
+// fp16 I/O modes (reference mtk::qr::qr<fp16_notc | fp16_tc_nocor>: io type half, src/tsqr.hpp:38-39): the boundary converts, the
+// factorisation runs on the fp32 pipeline.  One thread moves eight consecutive rows of one column: a 16-byte fp16 access when the
+// fp16 side is 16-byte aligned (vec = 1: base pointer and leading dimension), element by element otherwise; ragged tails by element.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void widen_f16_kernel(float* __restrict__ dst, size_t ldd, const _Float16* __restrict__ src, size_t lds,
+                                                        size_t rows, int cols, int vec) {
+	const size_t rb = (rows + 7) / 8, total = rb * (size_t)cols;
+	for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)256 * gridDim.x) {
+		const size_t col = idx / rb, row = (idx % rb) * 8;
+		const _Float16* s = src + col * lds + row;
+		float* d = dst + col * ldd + row;
+		if (vec && row + 8 <= rows) {
+			const f16x8 h = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(s));
+			*reinterpret_cast<f32x4*>(d) = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+			*reinterpret_cast<f32x4*>(d + 4) = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+		} else {
+			for (int i = 0; i < 8 && row + i < rows; i++) d[i] = (float)s[i];
+		}
+	}
+}
+// (round to nearest even; values beyond the fp16 range become infinities, as a half-typed R does in the reference)
+__global__ __launch_bounds__(256) void narrow_f16_kernel(_Float16* __restrict__ dst, size_t ldd, const float* __restrict__ src, size_t lds,
+                                                         size_t rows, int cols, int vec) {
+	const size_t rb = (rows + 7) / 8, total = rb * (size_t)cols;
+	for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)256 * gridDim.x) {
+		const size_t col = idx / rb, row = (idx % rb) * 8;
+		const float* s = src + col * lds + row;
+		_Float16* d = dst + col * ldd + row;
+		if (vec && row + 8 <= rows) {
+			const f32x4 a = *reinterpret_cast<const f32x4u*>(s), b = *reinterpret_cast<const f32x4u*>(s + 4);
+			const f16x8 h = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+			__builtin_nontemporal_store(h, reinterpret_cast<f16x8*>(d));
+		} else {
+			for (int i = 0; i < 8 && row + i < rows; i++) d[i] = (_Float16)s[i];
+		}
+	}
 }
 
 __global__ __launch_bounds__(256) void copy2d_kernel(float* __restrict__ dst, size_t ldd, const float* __restrict__ src, size_t lds,

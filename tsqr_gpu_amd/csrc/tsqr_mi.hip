@@ -1129,6 +1129,54 @@ int tsqr_mi_qr_f32_loop(int count, int mode, int reorth, float* q, size_t ldq, f
 	return TSQR_MI_SUCCESS;
 }
 
+// ---- fp16 I/O modes: reference mtk::qr::qr<fp16_notc | fp16_tc_nocor, Reorthogonalize> (src/blockqr.cu:437-449; io and working
+// types half, src/tsqr.hpp:27-39).  The boundary converts, the factorisation is the fp32 pipeline: A is widened into the tail of
+// wq (leading dimension = m rounded up to 128: full blocks for the fast kernels), Q and R are formed in fp32 next to it and
+// rounded to fp16 on the way out.  fp16_notc runs the exact-fp32-MFMA apply engine, fp16_tc_nocor the single-fp16-product engine
+// (exact for fp16 data in A; inverse(R) rounded to fp16, no correction -- the mode's meaning in the reference, src/tcqr32x16.cu:617-667).
+// A is never modified.  Costs two conversion passes on top of the fp32 call (profiles/r03_experiment_log.md). ----
+namespace {
+size_t f16_ld(size_t m) { return (m + 127) & ~(size_t)127; }
+size_t f16_tail_offset(size_t m, size_t n) { return (tsqr_mi_working_q_size(m, n) + 63) & ~(size_t)63; }
+int f16_engine_mode(int mode) {
+	if (mode == TSQR_MI_FP16_NOTC) return TSQR_MI_FP32_NOTC;
+	if (mode == TSQR_MI_FP16_TC_NOCOR) return TSQR_MI_FP32_TC_NOCOR;
+	return -1;
+}
+}  // namespace
+size_t tsqr_mi_working_q_size_f16(size_t m, size_t n) {
+	if (m == 0 || n == 0) return 0;
+	return f16_tail_offset(m, n) + 2 * f16_ld(m) * n + ((n * n + 63) & ~(size_t)63);
+}
+size_t tsqr_mi_working_r_size_f16(size_t m, size_t n) { return tsqr_mi_working_r_size(m, n); }
+
+int tsqr_mi_qr_f16(int mode, int reorth, void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
+                   size_t m, size_t n, void* wq_v, void* wr_v, void* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
+	(void)reorth_w;
+	if (n > m || m == 0 || n == 0) return TSQR_MI_ERROR_INVALID_SIZE;
+	const int emode = f16_engine_mode(mode);
+	if (emode < 0) { t_last_error = "tsqr_mi_qr_f16 takes fp16_notc or fp16_tc_nocor"; return TSQR_MI_ERROR_UNSUPPORTED; }
+	if (ldq < m || lda < m || ldr < n) return TSQR_MI_ERROR_INVALID_SIZE;
+	hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+	const size_t ld32 = f16_ld(m);
+	float* a32 = reinterpret_cast<float*>(wq_v) + f16_tail_offset(m, n);
+	float* q32 = a32 + ld32 * n;
+	float* r32 = q32 + ld32 * n;
+	auto aligned16 = [](const void* p, size_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
+	const unsigned grid = (unsigned)std::min<size_t>(4096, cdiv(cdiv(m, 8) * n, 256));
+	hipLaunchKernelGGL(tsqrmi::widen_f16_kernel, dim3(grid), dim3(256), 0, st, a32, ld32, reinterpret_cast<const _Float16*>(a), lda, m, (int)n,
+	                   aligned16(a, lda) ? 1 : 0);
+	HIPCHK(hipGetLastError());
+	const int rc = tsqr_mi_qr_f32(emode, reorth, q32, ld32, r32, n, a32, ld32, m, n, wq_v, wr_v, nullptr, d_wl, h_wl, stream);   // (blocking)
+	if (rc) return rc;
+	hipLaunchKernelGGL(tsqrmi::narrow_f16_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<_Float16*>(q), ldq, q32, ld32, m, (int)n,
+	                   aligned16(q, ldq) ? 1 : 0);
+	hipLaunchKernelGGL(tsqrmi::narrow_f16_kernel, dim3((unsigned)cdiv(cdiv(n, 8) * n, 256)), dim3(256), 0, st, reinterpret_cast<_Float16*>(r), ldr, r32, n,
+	                   n, (int)n, aligned16(r, ldr) ? 1 : 0);
+	HIPCHK(hipGetLastError());
+	return tsqr_mi_stream_wait(stream);
+}
+
 // ---- row-partitioned TSQR: one call per rank, the same ladder as tsqr_mi_qr_f32 with the exchange hooks switched on ----
 int tsqr_mi_qr_f32_dist_fn(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                            size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,

@@ -67,10 +67,20 @@ def residual(q, r, a, m, n, ldq=None, ldr=None, lda=None):
 
 
 # ---- engine wrapper -------------------------------------------------------------------------------------------------
+def io_dtype(mode):
+    """element type of q, r, a for a compute mode (reference src/tsqr.hpp:36-39): half for the two fp16 I/O modes, float otherwise"""
+    return torch.float16 if bq.compute_mode(mode) in bq.FP16_MODES else torch.float32
+
+
+def io_name(mode):
+    return "half" if bq.compute_mode(mode) in bq.FP16_MODES else "float"
+
+
 def qr(a, m, n, mode, reorth, bf=None):
-    """(state, Q, R) of the column-major m x n matrix held by tensor `a` ((n, m) row-major); `a` may be clobbered for n > 64."""
-    q = torch.empty(n, m, dtype=torch.float32, device=a.device)
-    r = torch.zeros(n, n, dtype=torch.float32, device=a.device)         # caller pre-zeros R (src/test.cu:129)
+    """(state, Q, R) of the column-major m x n matrix held by tensor `a` ((n, m) row-major, of the mode's io type); `a` may be
+    clobbered for n > 64 (fp32 modes)."""
+    q = torch.empty(n, m, dtype=io_dtype(mode), device=a.device)
+    r = torch.zeros(n, n, dtype=io_dtype(mode), device=a.device)         # caller pre-zeros R (src/test.cu:129)
     if bf is None:
         bf = bq.buffer(mode, reorth, device=a.device)
         bf.allocate(m, n)
@@ -160,14 +170,14 @@ def accuracy(matrix_config_list, C=16, mode=bq.compute_mode.fp32_tc_cor, reorth=
         bf.allocate(m, n)
         res, orth = [], []
         for _ in range(C):
-            a = (torch.rand(n, m, generator=gen, device="cuda", dtype=torch.float32) * 2 - 1) * rr
-            a0 = a.clone()                                           # the engine may clobber a (n > 64)
+            a = ((torch.rand(n, m, generator=gen, device="cuda", dtype=torch.float32) * 2 - 1) * rr).to(io_dtype(mode))
+            a0 = a.float() if a.dtype != torch.float32 else a.clone()    # the engine may clobber a (n > 64); metrics are taken in fp64 from fp32 copies
             st, q, r = qr(a, m, n, mode, reorth, bf)
             assert st == 0
-            res.append(residual(q, r, a0, m, n))
-            orth.append(check_orthogonality16(q, m, n))
+            res.append(residual(q.float(), r.float(), a0, m, n))
+            orth.append(check_orthogonality16(q.float(), m, n))
         (rm, rv), (om, ov) = _mean_var(res), _mean_var(orth)
-        line = "%d,%d,%g,float,%s,%d,%e,%e,%e,%e" % (m, n, rr, bq.compute_mode(mode).name, int(reorth), rm, rv, om, ov)
+        line = "%d,%d,%g,%s,%s,%d,%e,%e,%e,%e" % (m, n, rr, io_name(mode), bq.compute_mode(mode).name, int(reorth), rm, rv, om, ov)
         print(line, file=out, flush=True)
         rows.append((m, n, rm, rv, om, ov))
     return rows
@@ -182,9 +192,9 @@ def speed(matrix_config_list, C=16, mode=bq.compute_mode.fp32_tc_cor, reorth=Fal
     for (m, n, rr) in matrix_config_list:
         gen = torch.Generator(device="cuda")
         gen.manual_seed(seed)
-        a = (torch.rand(n, m, generator=gen, device="cuda", dtype=torch.float32) * 2 - 1) * rr
-        q = torch.empty(n, m, dtype=torch.float32, device="cuda")
-        r = torch.zeros(n, n, dtype=torch.float32, device="cuda")
+        a = ((torch.rand(n, m, generator=gen, device="cuda", dtype=torch.float32) * 2 - 1) * rr).to(io_dtype(mode))
+        q = torch.empty(n, m, dtype=io_dtype(mode), device="cuda")
+        r = torch.zeros(n, n, dtype=io_dtype(mode), device="cuda")
         bf = bq.buffer(mode, reorth)
         bf.allocate(m, n)
         bq.qr(q, m, r, n, a, m, m, n, bf)
@@ -195,7 +205,7 @@ def speed(matrix_config_list, C=16, mode=bq.compute_mode.fp32_tc_cor, reorth=Fal
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / C
         tf = reference_flop_formula(m, n) / el / 1024.0 ** 4
-        print("%d,%d,%g,float,%s,%d,%e,%e,%d" % (m, n, rr, bq.compute_mode(mode).name, int(reorth), el, tf,
+        print("%d,%d,%g,%s,%s,%d,%e,%e,%d" % (m, n, rr, io_name(mode), bq.compute_mode(mode).name, int(reorth), el, tf,
                                                   bf.get_device_memory_size()), file=out, flush=True)
         rows.append((m, n, el, tf))
     return rows
@@ -212,14 +222,14 @@ def accuracy_cond(matrix_config_list, C=8, mode=bq.compute_mode.fp32_tc_cor, reo
         bf.allocate(m, n)
         res, orth = [], []
         for c in range(C):
-            a = get_rand_matrix_with_cond_number(m, n, float(cond), seed=seed + c)
-            a0 = a.clone()
+            a = get_rand_matrix_with_cond_number(m, n, float(cond), seed=seed + c).to(io_dtype(mode))
+            a0 = a.float() if a.dtype != torch.float32 else a.clone()
             st, q, r = qr(a, m, n, mode, reorth, bf)
             assert st == 0
-            res.append(residual(q, r, a0, m, n))
-            orth.append(check_orthogonality16(q, m, n))
+            res.append(residual(q.float(), r.float(), a0, m, n))
+            orth.append(check_orthogonality16(q.float(), m, n))
         (rm, rv), (om, ov) = _mean_var(res), _mean_var(orth)
-        print("%d,%d,%g,float,%s,%d,%e,%e,%e,%e" % (m, n, cond, bq.compute_mode(mode).name, int(reorth), rm, rv, om, ov),
+        print("%d,%d,%g,%s,%s,%d,%e,%e,%e,%e" % (m, n, cond, io_name(mode), bq.compute_mode(mode).name, int(reorth), rm, rv, om, ov),
               file=out, flush=True)
         rows.append((m, n, cond, rm, rv, om, ov))
     return rows
