@@ -27,8 +27,8 @@ extern "C" {
 
 /* mtk::qr::compute_mode, same names and order as reference src/blockqr.hpp:12-23 */
 enum tsqr_mi_compute_mode {
-	TSQR_MI_FP16_NOTC = 0,         /* supported through tsqr_mi_qr_f16: fp16 in / out, the fp32_notc pipeline in between */
-	TSQR_MI_FP16_TC_NOCOR = 1,     /* supported through tsqr_mi_qr_f16: fp16 in / out, the fp32_tc_nocor pipeline in between */
+	TSQR_MI_FP16_NOTC = 0,         /* supported through tsqr_mi_qr_f16: fp16 in / out, fp32-accurate arithmetic in between (the fp32_tc_cor engines) */
+	TSQR_MI_FP16_TC_NOCOR = 1,     /* supported through tsqr_mi_qr_f16: fp16 in / out, the single-fp16-product apply engine (fp32_tc_nocor's) */
 	TSQR_MI_FP32_NOTC = 2,         /* supported: Q = A*inverse(R) on exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
 	TSQR_MI_FP32_TC_COR = 3,       /* supported: Q = A*inverse(R) on bf16 MFMA with 3-way split error correction (six products) */
 	TSQR_MI_FP32_TC_NOCOR = 4,     /* supported: R as fp32_tc_cor; Q = A*inverse(R) on fp16 MFMA, one product, no correction */
@@ -88,10 +88,13 @@ int tsqr_mi_qr_f32_loop(int count, int mode, int reorth,
 /*
  * The fp16 I/O modes: replaces mtk::qr::qr<fp16_notc | fp16_tc_nocor, Reorthogonalize> (reference src/blockqr.cu:437-449; io type
  * half, src/tsqr.hpp:38-39).  q, r, a are IEEE binary16 (`half` / `_Float16`), column-major like the fp32 entry; everything else
- * as tsqr_mi_qr_f32.  The factorisation itself is the fp32 pipeline -- A is widened into the work buffer, Q and R are rounded to
- * fp16 (nearest even) on the way out -- so the result is the fp16 rounding of an fp32-accurate factorisation (the reference computes
- * these modes IN half).  fp16_notc uses the exact-fp32 apply engine, fp16_tc_nocor the single-fp16-product engine.  A is not
- * modified.  R entries beyond the fp16 range (column norms > 65504) become infinities, as a half-typed R does in the reference.
+ * as tsqr_mi_qr_f32.  Arithmetic is this engine's fp32 pipeline with fp16 at the boundary, so the result is the fp16 rounding of an
+ * fp32-accurate factorisation (the reference computes these modes IN half): fp16_notc forms Q with the error-corrected bf16x3
+ * products of fp32_tc_cor, fp16_tc_nocor with one fp16 product (inverse(R) rounded to fp16, no correction).  One panel (n <= 64),
+ * no reorthogonalisation, 16-byte aligned columns (base pointers, lda and ldq multiples of 8) and a matrix the bf16-split level
+ * accepts take the NATIVE path: the Gram pass uses the halves of A as MFMA operands (exact products), the apply pass reads and
+ * writes halves -- half the bytes of the fp32 call.  Everything else is widened into the work buffer, factored by tsqr_mi_qr_f32
+ * and narrowed on the way out (two conversion passes).  A is not modified.  R entries beyond the fp16 range (column norms > 65504) become infinities, as a half-typed R does in the reference.
  * Work space: wq of tsqr_mi_working_q_size_f16(m, n) FLOATS (4-byte units: the fp32 call's own space + the widened A, Q and R),
  * wr of tsqr_mi_working_r_size_f16(m, n) floats, d_wl / h_wl as for the fp32 entry.  n <= m, any n.
  */
@@ -102,6 +105,12 @@ int tsqr_mi_qr_f16(int mode, int reorth,
                    size_t m, size_t n,
                    void* wq, void* wr, void* reorth_w, unsigned* d_wl, unsigned* h_wl,
                    void* stream);
+/* `count` back-to-back blocking calls (the reference's speed loop, src/test.cu:299-309, as tsqr_mi_qr_f32_loop) */
+int tsqr_mi_qr_f16_loop(int count, int mode, int reorth,
+                        void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
+                        size_t m, size_t n,
+                        void* wq, void* wr, void* reorth_w, unsigned* d_wl, unsigned* h_wl,
+                        void* stream);
 
 /*
  * Staged entry points used by the row-partitioned multi-GPU path: every rank

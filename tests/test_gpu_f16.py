@@ -71,8 +71,8 @@ def test_fp16_modes(bq, oracle, torch_cuda, m, n, mode):
     q64, r64 = q.astype(np.float64), r.astype(np.float64)
     assert np.linalg.norm(q64 @ r64 - a64) / np.linalg.norm(a64) < RES_TOL
     assert np.linalg.norm(q64.T @ q64 - np.eye(n)) < ORTH_TOL * max(1.0, n / 100)        # (n^2 entries, each a sum of roundings of Q)
-    # the outputs are the fp16 roundings of the fp32 pipeline's result on the same data (same engine: fp32_notc / fp32_tc_nocor)
-    st32, q32, r32 = run_f32(bq, torch_cuda, a16.astype(np.float32), bq.compute_mode["fp32_notc" if mode == "fp16_notc" else "fp32_tc_nocor"], False)
+    # the outputs are the fp16 roundings of the fp32 pipeline's result on the same data (same apply engine: fp32_tc_cor / fp32_tc_nocor)
+    st32, q32, r32 = run_f32(bq, torch_cuda, a16.astype(np.float32), bq.compute_mode["fp32_tc_cor" if mode == "fp16_notc" else "fp32_tc_nocor"], False)
     assert st32 == 0
     ulp = 2.0 ** -10                                                         # (one unit in the last place of a value below 1; relative otherwise)
     assert np.abs(q.astype(np.float32) - q32).max() <= ulp * max(1.0, np.abs(q32).max())
@@ -100,7 +100,7 @@ def test_fp16_modes_reorthogonalised_ill_conditioned(bq, oracle, torch_cuda, mod
     assert st == 0 and np.isfinite(q).all() and np.isfinite(r).all()
     q64, r64 = q.astype(np.float64), r.astype(np.float64)
     # (fp16_tc_nocor: inverse(R) enters the apply pass rounded to fp16, one product, no correction -- its entries span the
-    # conditioning, so the residual carries a few roundings more than with the exact-fp32 engine of fp16_notc)
+    # conditioning, so the residual carries a few roundings more than with the error-corrected engine of fp16_notc)
     assert np.linalg.norm(q64 @ r64 - a64) / np.linalg.norm(a64) < (3 * RES_TOL if mode == "fp16_tc_nocor" else RES_TOL)
     assert np.linalg.norm(q64.T @ q64 - np.eye(n)) < ORTH_TOL
 
@@ -109,7 +109,7 @@ def test_fp16_r_beyond_the_half_range_is_infinite_like_a_half_typed_r(bq, oracle
     """column norms above 65504 cannot be stored in a half-typed R (the reference's io type): they come back as infinities, Q is unaffected"""
     m, n = 65536, 16
     a16 = (oracle.uniform_matrix(m, n, seed=9) * 1000.0).astype(np.float16)      # ||a_j|| ~ 1000 sqrt(m / 3) = 1.5e5
-    # (fp16_notc: the exact-fp32 apply engine.  The single-product engine of the *_tc_nocor modes rounds inverse(R) to fp16 without a
+    # (fp16_notc: the error-corrected apply engine.  The single-product engine of the *_tc_nocor modes rounds inverse(R) to fp16 without a
     # scale factor: with column norms of 1.5e5 its entries fall into the fp16 subnormal range and Q loses accuracy -- the range
     # limit of fp16 operands, DESIGN.md section 2)
     st, q, r = run_f16(bq, torch_cuda, a16, bq.compute_mode.fp16_notc, False)

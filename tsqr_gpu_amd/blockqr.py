@@ -46,7 +46,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_gram_elems", "tsqr_mi_gram_f32", "tsqr_mi_chol_f32", "tsqr_mi_chol_status", "tsqr_mi_stream_wait", "tsqr_mi_apply_z_f32", "tsqr_mi_validate_f32",
     "tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist", "tsqr_mi_qr_f32_dist_cb",
     "tsqr_mi_qr_f32_loop", "tsqr_mi_qr_f32_dist_fn", "tsqr_mi_qr_f32_dist_fn_loop", "tsqr_mi_qr_f32_dist_cb_loop",
-    "tsqr_mi_qr_f16", "tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16",
+    "tsqr_mi_qr_f16", "tsqr_mi_qr_f16_loop", "tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16",
 ]
 FP16_MODES = (compute_mode.fp16_notc, compute_mode.fp16_tc_nocor)     # io type half in the reference (src/tsqr.hpp:38-39)
 
@@ -104,6 +104,8 @@ def lib():
     L.tsqr_mi_qr_f32_loop.argtypes = [ci] + L.tsqr_mi_qr_f32.argtypes
     L.tsqr_mi_qr_f16.restype = ci
     L.tsqr_mi_qr_f16.argtypes = L.tsqr_mi_qr_f32.argtypes
+    L.tsqr_mi_qr_f16_loop.restype = ci
+    L.tsqr_mi_qr_f16_loop.argtypes = [ci] + L.tsqr_mi_qr_f32.argtypes
     for name in ("tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16"):
         getattr(L, name).restype = sz
         getattr(L, name).argtypes = [sz, sz]
@@ -262,7 +264,7 @@ def bind_loop(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthog
     if stream is None:
         stream = torch.cuda.current_stream()
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
-    fn = lib().tsqr_mi_qr_f32_loop
+    fn = lib().tsqr_mi_qr_f16_loop if mode in FP16_MODES else lib().tsqr_mi_qr_f32_loop      # (float16 tensors for the fp16 I/O modes)
     args = (ci(int(mode)), ci(int(reorth)), vp(_ptr(q)), sz(ldq), vp(_ptr(r)), sz(ldr), vp(_ptr(a)), sz(lda), sz(m), sz(n),
             vp(_ptr(bf.dwq)), vp(_ptr(bf.dwr)), vp(_ptr(bf.dw_reorth_r)), vp(_ptr(bf.dl)), vp(_ptr(bf.hl)), vp(stream.cuda_stream))
     keep = (q, r, a, bf, stream)

@@ -22,6 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global access
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. makes every wave wait for its global
 // loads AND stores in flight -- a prefetch issued before the barrier, or the streaming stores of the previous block, would then be
@@ -816,6 +817,107 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	}
 }
 
+// gram_h_kernel (round 3, fp16 I/O modes): the Gram tiles of an fp16 matrix straight from its halves -- lane (c,q) loads rows
+// 8q .. 8q+7 of a 32-row K-step of column 16t+c as ONE 16-byte access, which IS the operand of v_mfma_f32_16x16x32_f16: no
+// widening pass, no split (products of fp16 values are exact in the fp32 accumulator), ten MFMAs per K-step instead of sixty, half
+// the bytes of the fp32 pass.  One MFMA chain per 64-row chunk (64 accumulations per entry: far inside the chain lengths validated
+// for the bf16-split pass), fp64 totals; the next chunk's operands are requested before the current chunk's MFMAs.  Partials in the
+// format of gram_bf16_kernel.  The host sends lda % 8 == 0 and a 16-byte aligned base only (tsqr_mi_qr_f16 otherwise converts).
+template <int NT>
+__global__ __launch_bounds__(256) void gram_h_kernel(const GramArgs a) {
+	constexpr int NTRI = (NT * (NT + 1)) / 2;
+	__shared__ double red[2][NTRI * 256];
+	if (a.skip_status && a.skip_status[0] != 0) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int gw = blockIdx.x * 4 + wv;
+	const int c = lane & 15, q = lane >> 4;
+	const _Float16* A = reinterpret_cast<const _Float16*>(a.a);
+	f32x4 acc[NTRI];
+	f64x4 tot[NTRI];
+#pragma unroll
+	for (int t = 0; t < NTRI; t++) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[t] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+	auto load_chunk_h = [&](f16x8 (&op)[NT][2], int ch) {
+#pragma unroll
+		for (int t = 0; t < NT; t++)
+#pragma unroll
+			for (int kt = 0; kt < 2; kt++) {
+				const size_t row = (size_t)ch * 64 + 32 * kt + 8 * q;
+				const int col = 16 * t + c;
+				f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+				if (col < a.n) {
+					const _Float16* src = A + (size_t)col * a.lda + row;
+					if (row + 7 < a.m) v = *reinterpret_cast<const f16x8*>(src);
+					else {
+#pragma unroll
+						for (int i = 0; i < 8; i++)
+							if (row + i < a.m) v[i] = src[i];
+					}
+				}
+				op[t][kt] = v;
+			}
+	};
+	if (gw < a.nwaves) {
+		f16x8 cur[NT][2], nxt[NT][2];
+		int ch = gw;
+		if (ch < a.nchunks) load_chunk_h(cur, ch);
+		for (; ch < a.nchunks; ch += a.nwaves) {
+			const bool more = ch + a.nwaves < a.nchunks;     // wave-uniform
+			if (more) load_chunk_h(nxt, ch + a.nwaves);
+#pragma unroll
+			for (int kt = 0; kt < 2; kt++) {
+				int idx = 0;
+#pragma unroll
+				for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+					for (int tj = ti; tj < NT; tj++) {
+						acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[ti][kt], cur[tj][kt], acc[idx], 0, 0, 0);
+						idx++;
+					}
+			}
+#pragma unroll
+			for (int t = 0; t < NTRI; t++) {
+#pragma unroll
+				for (int r = 0; r < 4; r++) tot[t][r] += (double)acc[t][r];
+				acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+			}
+			if (more) {
+#pragma unroll
+				for (int t = 0; t < NT; t++) { cur[t][0] = nxt[t][0]; cur[t][1] = nxt[t][1]; }
+			}
+		}
+	}
+	// workgroup sum in fp64: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the partial
+	if (wv >= 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[wv - 2][(t * 4 + r) * 64 + lane] = tot[t][r];
+	}
+	__syncthreads();
+	if (wv < 2) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) tot[t][r] += red[wv][(t * 4 + r) * 64 + lane];
+	}
+	__syncthreads();
+	if (wv == 1) {
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) red[0][(t * 4 + r) * 64 + lane] = tot[t][r];
+	}
+	__syncthreads();
+	if (wv == 0) {
+		double* out = a.part + (size_t)blockIdx.x * NTRI * 256;
+#pragma unroll
+		for (int t = 0; t < NTRI; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) part_store(&out[(t * 4 + r) * 64 + lane], tot[t][r] + red[0][(t * 4 + r) * 64 + lane]);
+	}
+}
+
 // gram_blk_kernel (round 3): the same Gram tiles for FULL 64-column matrices, with the block pattern of the apply pass on the load
 // side.  gram_bf16_kernel's (c,q) register layout feeds the MFMAs without any exchange, but an instruction of it can only ask for
 // 64 contiguous bytes per column (sixteen columns, four lanes each): its load-only skeleton takes 47.6 us at 2^20 x 64 where the
@@ -1490,9 +1592,12 @@ struct ApplyArgs {
 // ---------------------------------------------------------------------------------------------
 // GRAMQ: additionally accumulate the Gram matrix Q^T Q of the rows this workgroup produces (bf16-split level, fp64 totals, same
 // partial format as gram_bf16_kernel) -- the second sweep of a reorthogonalisation then needs no Gram pass of its own.
-template <int ENGINE, int NT, bool UPD, int ROWS, bool GRAMQ, int NW = 4>
+// IO = _Float16 (fp16 I/O modes): a.a and a.q hold halves (8-byte aligned rows of four: the host checks lda, ldq % 4 == 0 and the
+// bases); a block is widened on its way into As and the result narrowed on its way out -- the products run on the same engines.
+template <int ENGINE, int NT, bool UPD, int ROWS, bool GRAMQ, int NW = 4, class IO = float>
 __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	static_assert(!GRAMQ || NW == 4, "the fused Gram accumulation is written for four waves");
+	static_assert(sizeof(IO) == 4 || (!UPD && !GRAMQ), "fp16 I/O: the plain product only");
 	constexpr int NP = 16 * NT;
 	constexpr int RS = ROWS + 4;                         // column stride of As (floats)
 	constexpr int LPC = ROWS / 4, CPI = 64 / LPC;        // lanes per column, columns per load instruction
@@ -1523,23 +1628,31 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	const int nblk = a.nchunks, nwg = a.nwaves;
 	auto blk = [&](int i) { return nblk - 1 - i; };      // (block order does not matter to the Infinity Cache: tools/seq_bench.py)
 	auto swz = [](int col) { return ((col >> 3) & 1) << 4; };
-	auto load_block = [&](f32x4 (&v)[NI], const float* base, size_t ld, int ncols, int b) {
+	auto load_block = [&](f32x4 (&v)[NI], const auto* base, size_t ld, int ncols, int b) {
+		using T = std::remove_cv_t<std::remove_pointer_t<decltype(base)>>;
 		const size_t row = (size_t)b * ROWS + lrow;
 #pragma unroll
 		for (int k = 0; k < NI; k++) {
 			const int col = (wv + NW * k) * CPI + lcol;
 			v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 			if (col < ncols) {
-				const float* src = base + (size_t)col * ld + row;
-				if (row + 3 < a.m) v[k] = *reinterpret_cast<const f32x4u*>(src);
-				else {
+				const T* src = base + (size_t)col * ld + row;
+				if (row + 3 < a.m) {
+					if constexpr (sizeof(T) == 2) {
+						const f16x4 h = *reinterpret_cast<const f16x4*>(src);
+						v[k] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+					} else {
+						v[k] = *reinterpret_cast<const f32x4u*>(src);
+					}
+				} else {
 #pragma unroll
 					for (int i = 0; i < 4; i++)
-						if (row + i < a.m) v[k][i] = src[i];
+						if (row + i < a.m) v[k][i] = (float)src[i];
 				}
 			}
 		}
 	};
+	const IO* a_in = reinterpret_cast<const IO*>(a.a);
 
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	f64x4 gtot[GRAMQ ? NTRI : 1];
@@ -1552,8 +1665,8 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	constexpr bool DEEP = (ROWS == 64 && !UPD) || NW == 8;
 	f32x4 v[NI], v2[DEEP ? NI : 1];
 	int bi = blockIdx.x;
-	if (bi < nblk) load_block(v, a.a, a.lda, a.n, blk(bi));
-	if constexpr (DEEP) { if (bi + nwg < nblk) load_block(v2, a.a, a.lda, a.n, blk(bi + nwg)); }
+	if (bi < nblk) load_block(v, a_in, a.lda, a.n, blk(bi));
+	if constexpr (DEEP) { if (bi + nwg < nblk) load_block(v2, a_in, a.lda, a.n, blk(bi + nwg)); }
 	// (the verdict word is looked at only now: its round trip runs under the loads just issued; a skipped launch has merely
 	// requested a block or two of an input that is valid either way)
 	if (a.skip_status && a.skip_status[0] != 0) return;  // uniform over the grid
@@ -1632,9 +1745,9 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 		if constexpr (DEEP) {
 #pragma unroll
 			for (int k = 0; k < NI; k++) v[k] = v2[k];
-			if (bi + 2 * nwg < nblk) load_block(v2, a.a, a.lda, a.n, blk(bi + 2 * nwg));
+			if (bi + 2 * nwg < nblk) load_block(v2, a_in, a.lda, a.n, blk(bi + 2 * nwg));
 		} else {
-			if (bi + nwg < nblk) load_block(v, a.a, a.lda, a.n, blk(bi + nwg));
+			if (bi + nwg < nblk) load_block(v, a_in, a.lda, a.n, blk(bi + nwg));
 		}
 		f32x4 cin[UPD ? NI : 1];
 		if constexpr (UPD) load_block(cin, a.q, a.ldq, a.n_out, b);
@@ -1835,6 +1948,18 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 				if (col < nout) {
 					f32x4 x = *reinterpret_cast<const f32x4*>(&As[col * RS + (lrow ^ swz(col))]);
 					if constexpr (UPD) x += cin[k];
+					if constexpr (sizeof(IO) == 2) {
+						_Float16* dh = reinterpret_cast<_Float16*>(a.q) + (size_t)col * a.ldq + row;
+						if (row + 3 < a.m) {
+							const f16x4 h = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+							__builtin_nontemporal_store(h, reinterpret_cast<f16x4*>(dh));
+						} else {
+#pragma unroll
+							for (int i = 0; i < 4; i++)
+								if (row + i < a.m) dh[i] = (_Float16)x[i];
+						}
+						continue;
+					}
 					float* dst = a.q + (size_t)col * a.ldq + row;
 					if (row + 3 < a.m) {
 						// Q must not displace A from the Infinity Cache: nontemporal.  The updated panel of a coupling step (UPD) is read
@@ -1890,6 +2015,11 @@ __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
 	apply_wg_body<ENGINE, NT, UPD, ROWS, false>(a);
 }
 // the variant that also accumulates Q^T Q: two waves per SIMD (the register allocator is told to stay within 256 registers)
+// fp16 I/O modes: the plain product with halves at both ends (tsqr_mi_qr_f16's native path)
+template <int ENGINE, int NT, int ROWS>
+__global__ __launch_bounds__(256) void apply_wg_h_kernel(const ApplyArgs a) {
+	apply_wg_body<ENGINE, NT, false, ROWS, false, 4, _Float16>(a);
+}
 template <int ENGINE, int NT, bool UPD, int ROWS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void apply_wg_gramq_kernel(const ApplyArgs a) {
 	apply_wg_body<ENGINE, NT, UPD, ROWS, true>(a);
@@ -1964,7 +2094,6 @@ __global__ void host_flag_kernel(unsigned* __restrict__ host_flag, unsigned seq)
 // fp16 I/O modes (reference mtk::qr::qr<fp16_notc | fp16_tc_nocor>: io type half, src/tsqr.hpp:38-39): the boundary converts, the
 // factorisation runs on the fp32 pipeline.  One thread moves eight consecutive rows of one column: a 16-byte fp16 access when the
 // fp16 side is 16-byte aligned (vec = 1: base pointer and leading dimension), element by element otherwise; ragged tails by element.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void widen_f16_kernel(float* __restrict__ dst, size_t ldd, const _Float16* __restrict__ src, size_t lds,
                                                         size_t rows, int cols, int vec) {
 	const size_t rb = (rows + 7) / 8, total = rb * (size_t)cols;

@@ -452,7 +452,8 @@ template <int NT> void launch_gram(const tsqrmi::GramArgs& a, int nblocks, bool 
 
 // Gram matrix of src (m x n) in MFMA-accumulator order -> c.gsum() (ntri*256 doubles + the local row count behind them), summed
 // over the ranks of a row-partitioned call.  bf16 = true: bf16x3-split MFMA (memory-bound, f32 C/D layout), false: fp64 MFMA.
-int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16) {
+// io_half: src holds halves (fp16 I/O modes, bf16 level only): gram_h_kernel takes them as MFMA operands directly.
+int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16, bool io_half = false) {
 	const GramPlan g = gram_plan(m, n);
 	const int NT = (int)(np_of(n) / 16);
 	tsqrmi::GramArgs a{};
@@ -463,6 +464,14 @@ int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16) {
 	if (bf16 && c.gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		c.gramq_ready = false;
 		nparts = c.gramq_nparts;
+	} else if (io_half) {
+		ProfScope ps(KC_GRAM, c.st);
+		switch (NT) {
+			case 1: hipLaunchKernelGGL(tsqrmi::gram_h_kernel<1>, dim3(g.nblocks), dim3(256), 0, c.st, a); break;
+			case 2: hipLaunchKernelGGL(tsqrmi::gram_h_kernel<2>, dim3(g.nblocks), dim3(256), 0, c.st, a); break;
+			case 3: hipLaunchKernelGGL(tsqrmi::gram_h_kernel<3>, dim3(g.nblocks), dim3(256), 0, c.st, a); break;
+			default: hipLaunchKernelGGL(tsqrmi::gram_h_kernel<4>, dim3(g.nblocks), dim3(256), 0, c.st, a); break;
+		}
 	} else if (bf16 && n == 64 && m % 128 == 0 && m <= ((size_t)1 << 20) && ld % 4 == 0 && ld <= ((size_t)1 << 24) && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
 		// full 64-column matrices that fit the 256 MiB Infinity Cache: block-pattern loads + LDS staging (gram_blk_kernel); everything
 		// else: gram_bf16_kernel.  (Measured, kernel / call period under the profiler: 2^21 rows 93.8 / 322.6 vs 95.8 / 319.4 us,
@@ -572,6 +581,40 @@ template <int E, int NT, bool UPD> int launch_apply_any(Ctx& c, const tsqrmi::Ap
 	if constexpr (!UPD && E == 1) return launch_apply_wg<E, NT, UPD, 64>(c, a);
 	else return launch_apply_wg<E, NT, UPD, 128>(c, a);
 }
+// fp16 I/O modes: the plain product with halves at both ends -- bf16x3 engine 1 (fp16_notc: 64-row blocks, four workgroups per CU,
+// like the fp32 call) or single-fp16-product engine 2 (fp16_tc_nocor: 128-row blocks)
+template <int E, int NT> int launch_apply_h(Ctx& c, tsqrmi::ApplyArgs a) {
+	constexpr int ROWS = (E == 1) ? 64 : 128;
+	constexpr auto kernel = &tsqrmi::apply_wg_h_kernel<E, NT, ROWS>;
+	constexpr int NP = 16 * NT, KT = (NP + 31) / 32;
+	constexpr int NB = (NT == 4) ? 6 : KT * NT;
+	const size_t lds = sizeof(float) * NP * (ROWS + 4) + (E == 0 ? sizeof(float) * NP * (NP + 16) : (size_t)(E == 2 ? 1 : 3) * NB * 512 * 2);
+	static DevOnce attr;
+	static std::atomic<int> per_cu_cache[MAX_DEV];
+	if (attr.need(c.dev)) {
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), 256, lds) != hipSuccess || nb < 1) {
+			(void)hipGetLastError(); nb = 2;
+		}
+		per_cu_cache[c.dev].store(std::min(nb, ROWS == 64 ? 4 : 3));
+		attr.done(c.dev);
+	}
+	const size_t nblk = cdiv(a.m, (size_t)ROWS);
+	a.nchunks = (int)nblk;
+	a.nwaves = (int)std::min<size_t>(nblk, (size_t)256 * per_cu_cache[c.dev].load());
+	a.cpw = 0;
+	hipLaunchKernelGGL(kernel, dim3(a.nwaves), dim3(256), lds, c.st, a);
+	return 0;
+}
+template <int E> int dispatch_apply_h(Ctx& c, int NT, const tsqrmi::ApplyArgs& a) {
+	switch (NT) {
+		case 1: return launch_apply_h<E, 1>(c, a);
+		case 2: return launch_apply_h<E, 2>(c, a);
+		case 3: return launch_apply_h<E, 3>(c, a);
+		default: return launch_apply_h<E, 4>(c, a);
+	}
+}
 template <int E> int dispatch_apply_nt(Ctx& c, int NT, const tsqrmi::ApplyArgs& a) {
 	switch (NT) {
 		case 1: return launch_apply_any<E, 1, false>(c, a);
@@ -582,8 +625,9 @@ template <int E> int dispatch_apply_nt(Ctx& c, int NT, const tsqrmi::ApplyArgs& 
 }
 
 // q = a * inverse(r); n <= 64; Z in wq[L.z] (computed here from r unless z_ready)
+// io_half: a and q hold halves (fp16 I/O modes; engines 1 and 2)
 int apply_rinv(Ctx& c, int engine, float* q, size_t ldq, const float* a, size_t lda, const float* r, size_t ldr,
-               size_t m, size_t n, bool z_ready = false, const unsigned* skip_status = nullptr) {
+               size_t m, size_t n, bool z_ready = false, const unsigned* skip_status = nullptr, bool io_half = false) {
 	const size_t NP = np_of(n);
 	const int NT = (int)(NP / 16);
 	float* z_buf = c.wq + c.L.z;
@@ -597,7 +641,8 @@ int apply_rinv(Ctx& c, int engine, float* q, size_t ldq, const float* a, size_t 
 	int rc;
 	{
 		ProfScope ps(KC_APPLY, c.st);
-		rc = (engine == 0) ? dispatch_apply_nt<0>(c, NT, aa) : (engine == 1 ? dispatch_apply_nt<1>(c, NT, aa) : dispatch_apply_nt<2>(c, NT, aa));
+		if (io_half) rc = (engine == 1) ? dispatch_apply_h<1>(c, NT, aa) : dispatch_apply_h<2>(c, NT, aa);
+		else rc = (engine == 0) ? dispatch_apply_nt<0>(c, NT, aa) : (engine == 1 ? dispatch_apply_nt<1>(c, NT, aa) : dispatch_apply_nt<2>(c, NT, aa));
 	}
 	if (rc) return rc;
 	HIPCHK(hipGetLastError());
@@ -1132,14 +1177,16 @@ int tsqr_mi_qr_f32_loop(int count, int mode, int reorth, float* q, size_t ldq, f
 // ---- fp16 I/O modes: reference mtk::qr::qr<fp16_notc | fp16_tc_nocor, Reorthogonalize> (src/blockqr.cu:437-449; io and working
 // types half, src/tsqr.hpp:27-39).  The boundary converts, the factorisation is the fp32 pipeline: A is widened into the tail of
 // wq (leading dimension = m rounded up to 128: full blocks for the fast kernels), Q and R are formed in fp32 next to it and
-// rounded to fp16 on the way out.  fp16_notc runs the exact-fp32-MFMA apply engine, fp16_tc_nocor the single-fp16-product engine
-// (exact for fp16 data in A; inverse(R) rounded to fp16, no correction -- the mode's meaning in the reference, src/tcqr32x16.cu:617-667).
-// A is never modified.  Costs two conversion passes on top of the fp32 call (profiles/r03_experiment_log.md). ----
+// rounded to fp16 on the way out.  fp16_notc runs the error-corrected bf16x3 apply engine (fp32-accurate products: the pipeline of
+// fp32_tc_cor), fp16_tc_nocor the single-fp16-product engine (exact for fp16 data in A; inverse(R) rounded to fp16, no correction --
+// the mode's meaning in the reference, src/tcqr32x16.cu:617-667).
+// A is never modified.  Costs two conversion passes on top of the fp32 call -- unless the native path inside tsqr_mi_qr_f16 takes
+// the call (one panel, one sweep, aligned columns, accepted by the bf16-split level's verdict). ----
 namespace {
 size_t f16_ld(size_t m) { return (m + 127) & ~(size_t)127; }
 size_t f16_tail_offset(size_t m, size_t n) { return (tsqr_mi_working_q_size(m, n) + 63) & ~(size_t)63; }
 int f16_engine_mode(int mode) {
-	if (mode == TSQR_MI_FP16_NOTC) return TSQR_MI_FP32_NOTC;
+	if (mode == TSQR_MI_FP16_NOTC) return TSQR_MI_FP32_TC_COR;
 	if (mode == TSQR_MI_FP16_TC_NOCOR) return TSQR_MI_FP32_TC_NOCOR;
 	return -1;
 }
@@ -1164,6 +1211,35 @@ int tsqr_mi_qr_f16(int mode, int reorth, void* q, size_t ldq, void* r, size_t ld
 	float* r32 = q32 + ld32 * n;
 	auto aligned16 = [](const void* p, size_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
 	const unsigned grid = (unsigned)std::min<size_t>(4096, cdiv(cdiv(m, 8) * n, 256));
+	// Native path (one panel, one sweep, auto policy, 16-byte aligned columns): the Gram pass takes the halves of A as MFMA operands
+	// (gram_h_kernel: exact products, half the bytes), the apply pass reads halves and writes halves -- no conversion passes.  The
+	// verdict is the bf16-split level's; a rejected matrix (A untouched) goes through the conversion path below and its whole ladder.
+	if (n <= PW && !reorth && g_set.policy.load() == 0 && g_set.gram_level.load() == 2 && aligned16(a, lda) && aligned16(q, ldq)) {
+		Ctx c;
+		init_ctx(c, wq_v, wr_v, m, n, stream);
+		c.rows_global = (double)m;
+		resolve_host_sig(c, h_wl, m);
+		c.slot = 0; c.prev_slot = -1;
+		int rc = gram_g(c, reinterpret_cast<const float*>(a), lda, m, n, /*bf16=*/true, /*io_half=*/true);
+		if (!rc) rc = chol_from_g(c, r32, n, n, 2);
+		if (!rc) {
+			// (R to fp16 by its own small launch, in front of the apply pass: scattered 2-byte stores inside the Cholesky kernel cost it 5 us)
+			hipLaunchKernelGGL(tsqrmi::narrow_f16_kernel, dim3((unsigned)cdiv(cdiv(n, 8) * n, 256)), dim3(256), 0, st, reinterpret_cast<_Float16*>(r), ldr, r32, n,
+			                   n, (int)n, aligned16(r, ldr) ? 1 : 0);
+			HIPCHK(hipGetLastError());
+			rc = apply_rinv(c, engine_of(f16_engine_mode(mode)), reinterpret_cast<float*>(q), ldq, reinterpret_cast<const float*>(a), lda,
+			                r32, n, m, n, /*z_ready=*/true, c.status_dev(0), /*io_half=*/true);
+		}
+		if (rc) return rc;
+		unsigned status = 1u;
+		float scond = 0.0f;
+		rc = read_status(c, 0, &status, &scond);
+		if (rc) return rc;
+		if (status == 0 && !(n <= 16 && scond > 32.0f)) {    // (n <= 16 with S > 32: the fp32 path adds a second sweep, see qr_core)
+			t_last_engine = 3;
+			return TSQR_MI_SUCCESS;
+		}
+	}
 	hipLaunchKernelGGL(tsqrmi::widen_f16_kernel, dim3(grid), dim3(256), 0, st, a32, ld32, reinterpret_cast<const _Float16*>(a), lda, m, (int)n,
 	                   aligned16(a, lda) ? 1 : 0);
 	HIPCHK(hipGetLastError());
@@ -1175,6 +1251,15 @@ int tsqr_mi_qr_f16(int mode, int reorth, void* q, size_t ldq, void* r, size_t ld
 	                   n, (int)n, aligned16(r, ldr) ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	return tsqr_mi_stream_wait(stream);
+}
+
+int tsqr_mi_qr_f16_loop(int count, int mode, int reorth, void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
+                        size_t m, size_t n, void* wq_v, void* wr_v, void* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
+	for (int i = 0; i < count; i++) {
+		const int st = tsqr_mi_qr_f16(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
+		if (st) return st;
+	}
+	return TSQR_MI_SUCCESS;
 }
 
 // ---- row-partitioned TSQR: one call per rank, the same ladder as tsqr_mi_qr_f32 with the exchange hooks switched on ----
