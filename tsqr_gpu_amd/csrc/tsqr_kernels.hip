@@ -1662,7 +1662,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	}
 	// the first block's loads are issued before Z is staged: their HBM latency overlaps the staging work
 	// prefetch: the next block in registers (v); 64-row blocks are small enough to keep the block after it in flight as well (v2)
-	constexpr bool DEEP = (ROWS == 64 && !UPD) || NW == 8;
+	constexpr bool DEEP = (ROWS == 64 && !UPD) || NW == 8 || sizeof(IO) == 2;      // (half I/O: a block is half the bytes -- keep two in flight)
 	f32x4 v[NI], v2[DEEP ? NI : 1];
 	int bi = blockIdx.x;
 	if (bi < nblk) load_block(v, a_in, a.lda, a.n, blk(bi));
