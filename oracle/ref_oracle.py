@@ -18,6 +18,8 @@ _SO = os.path.join(_HERE, "libref_oracle.so")
 FP32_NOTC = 2
 FP32_TC_COR = 3
 FP32_TC_NOCOR = 4
+FP16_NOTC = 0          # half-typed modes: pass / receive float32 arrays holding fp16 values (qr() rounds its input)
+FP16_TC_NOCOR = 1
 
 
 def build(force=False):
@@ -61,6 +63,8 @@ def qr(a, mode=FP32_TC_COR, reorth=False):
     clobbers its input for n > 16; the clobbered copy is discarded here).
     """
     a = np.asarray(a, dtype=np.float32)
+    if int(mode) in (FP16_NOTC, FP16_TC_NOCOR):         # io type half (src/tsqr.hpp:38-39): the input enters as fp16 values
+        a = a.astype(np.float16).astype(np.float32)
     m, n = a.shape
     af = np.asfortranarray(a).copy(order="F")
     q = np.zeros((max(m, 1), max(n, 1)), dtype=np.float32, order="F")

@@ -2,7 +2,7 @@
  * oracle/ref_tsqr.c -- TEST INFRASTRUCTURE ONLY (not product code).
  *
  * CPU restatement, in plain C, of the algorithm of enp1s0/tsqr-gpu for the path
- *   mtk::qr::qr<fp32_notc|fp32_tc_cor|fp32_tc_nocor, Reorth>()      (src/blockqr.hpp:142-175)
+ *   mtk::qr::qr<fp32_notc|fp32_tc_cor|fp32_tc_nocor|fp16_notc|fp16_tc_nocor, Reorth>()      (src/blockqr.hpp:142-175)
  * written from the source text of the reference.  Each function cites the
  * reference file:line it follows.
  *
@@ -15,7 +15,10 @@
  * k-ascending fp32 FMA inside the 16x16 matmul cores, plain fp32 sums for the
  * Tensor-Core accumulate; fp32_tc_nocor: an fp16 accumulator fragment is rounded to fp16
  * once per mma_sync (K = 16), and cuBLAS SGEMM under CUBLAS_TENSOR_OP_MATH (src/blockqr.cu:64-68)
- * rounds its inputs to fp16 and accumulates in fp32.  What IS pinned, by formula, is checked in
+ * rounds its inputs to fp16 and accumulates in fp32; the half-typed modes (fp16_notc, fp16_tc_nocor: io and working types half,
+ * src/tsqr.hpp:27-39): half FMA chains with one rounding per step inside gemm_core's matmul cores (fp16_notc), and cublasHgemm
+ * with fp32 accumulation and ONE rounding of the result to half -- the assumption most favourable to the reference (an fp16
+ * accumulator over 2^20 rows would be far worse).  What IS pinned, by formula, is checked in
  * tests/test_oracle.py: batch-size rule, workspace sizes, error codes, metric
  * definitions, and agreement with LAPACK (scipy) up to column signs.
  *
@@ -28,7 +31,9 @@
 #include <string.h>
 #include <stddef.h>
 
-#define REF_FP32_NOTC   2   /* position in mtk::qr::compute_mode, src/blockqr.hpp:12-23 */
+#define REF_FP16_NOTC   0   /* position in mtk::qr::compute_mode, src/blockqr.hpp:12-23 */
+#define REF_FP16_TC_NOCOR 1
+#define REF_FP32_NOTC   2
 #define REF_FP32_TC_COR 3
 #define REF_FP32_TC_NOCOR 4
 
@@ -104,6 +109,19 @@ static void hx_notc(float *X, const float *H, unsigned nc) {
 	memcpy(X, out, sizeof(float) * 32 * nc);
 }
 
+/* fp16_notc: the same product with T = half (src/matmul.hpp:21-24 -> gemm_core matmul_core16x16<32, true>, not in tree): a half
+ * FMA chain, k ascending, one rounding to half per step (assumed: __hfma) */
+static void hx_h_notc(float *X, const float *H, unsigned nc) {
+	float out[32 * 32];
+	for (unsigned c = 0; c < nc; c++)
+		for (unsigned r = 0; r < 32; r++) {
+			float acc = 0.0f;
+			for (unsigned k = 0; k < 32; k++) acc = h16(fmaf(H[k * 32 + r], X[c * 32 + k], acc));
+			out[c * 32 + r] = acc;
+		}
+	memcpy(X, out, sizeof(float) * 32 * nc);
+}
+
 /* src/tcqr32x16.cu:669-819: per 16-column group, correction terms first (K as 2 x 16),
  * rescale 1.0, then the main term on top; fp32 accumulators. */
 static void hx_tc_cor(float *X, const float *H, unsigned nc) {
@@ -161,9 +179,10 @@ static void hx_tc_nocor(float *X, const float *H, unsigned nc, int acc_half) {
 static void tile_qr(int mode, float *q_out, size_t ldq, float *r_out, size_t ldr,
                     const float *a, size_t lda, unsigned rows, unsigned n, int q_half) {
 	float Rt[32 * 16], Qt[32 * 32], H[32 * 32], u[32];
+	const int hmode = (mode == REF_FP16_NOTC || mode == REF_FP16_TC_NOCOR);   /* Q_T = R_T = A_T = half (src/tsqr.hpp:27-39), H half (:42-43) */
 	for (unsigned c = 0; c < 16; c++)
 		for (unsigned r = 0; r < 32; r++)
-			Rt[c * 32 + r] = (c < n && r < rows) ? a[r + c * lda] : 0.0f;
+			Rt[c * 32 + r] = (c < n && r < rows) ? (hmode ? h16(a[r + c * lda]) : a[r + c * lda]) : 0.0f;
 	for (unsigned c = 0; c < 32; c++)
 		for (unsigned r = 0; r < 32; r++) Qt[c * 32 + r] = (r == c) ? 1.0f : 0.0f;
 
@@ -172,7 +191,8 @@ static void tile_qr(int mode, float *q_out, size_t ldq, float *r_out, size_t ldr
 		const float norm_u_0 = sqrtf(norm2_32(u, rows));
 		if (k < 32) {
 			const float sgn = (u[k] < 0.0f) ? -1.0f : 1.0f;   /* cutf::math::sign, sign(0)=+1 assumed */
-			u[k] += sgn * norm_u_0;
+			if (hmode) u[k] = h16(u[k] + h16(sgn * norm_u_0));    /* u_ptr[k] += cast<A_T>(...): a half addition (src/tcqr32x16.cu:1421-1423) */
+			else u[k] += sgn * norm_u_0;
 		}
 		const float norm2_u_1 = norm2_32(u, rows);
 		if (mode == REF_FP32_TC_COR) {
@@ -189,6 +209,15 @@ static void tile_qr(int mode, float *q_out, size_t ldq, float *r_out, size_t ldr
 					const float acc = uh[y] * uh[x] + ul[y] * uh[x] + uh[y] * ul[x];
 					H[x * 32 + y] = -acc + ((x == y) ? 1.0f : 0.0f);
 				}
+		} else if (mode == REF_FP16_TC_NOCOR) {
+			/* src/tcqr32x16.cu:140-184: u *= sqrt(2 / |u|^2) in half, one outer product per 16 x 16 fragment with an fp16 accumulator
+			 * (load_vector fragments: one product per entry), then H = I - that in half arithmetic */
+			const float alpha = sqrtf(2.0f / norm2_u_1);
+			float us[32];
+			for (unsigned i = 0; i < 32; i++) us[i] = h16(u[i] * alpha);
+			for (unsigned x = 0; x < 32; x++)
+				for (unsigned y = 0; y < 32; y++)
+					H[x * 32 + y] = h16(((x == y) ? 1.0f : 0.0f) - h16(us[y] * us[x]));
 		} else if (mode == REF_FP32_TC_NOCOR) {
 			/* src/tcqr32x16.cu:186-226: H in fp16; one outer product per 16 x 16 fragment with an fp16 accumulator:
 			 * H(y, x) = half(delta - half(half(u_y * alpha) * half(u_x))), alpha = 2 / |u|^2 */
@@ -205,11 +234,13 @@ static void tile_qr(int mode, float *q_out, size_t ldq, float *r_out, size_t ldr
 				for (unsigned x = 0; x < 32; x++) {
 					float tmp = (x == y) ? 1.0f : 0.0f;
 					if (x < rows && y < rows) tmp -= uy * u[x];
-					H[x * 32 + y] = tmp;
+					H[x * 32 + y] = hmode ? h16(tmp) : tmp;              /* cast<T>(tmp): T = half for fp16_notc (:42) */
 				}
 			}
 		}
-		if (mode == REF_FP32_TC_COR)        { hx_tc_cor(Qt, H, 32); hx_tc_cor(Rt, H, 16); }
+		if (mode == REF_FP16_NOTC)          { hx_h_notc(Qt, H, 32); hx_h_notc(Rt, H, 16); }                  /* :464-496 with T = half */
+		else if (mode == REF_FP16_TC_NOCOR) { hx_tc_nocor(Qt, H, 32, 1); hx_tc_nocor(Rt, H, 16, 1); }        /* :617-667: half accumulator fragments for Q and R */
+		else if (mode == REF_FP32_TC_COR)   { hx_tc_cor(Qt, H, 32); hx_tc_cor(Rt, H, 16); }
 		else if (mode == REF_FP32_TC_NOCOR) { hx_tc_nocor(Qt, H, 32, q_half); hx_tc_nocor(Rt, H, 16, 0); }
 		else                                { hx_notc(Qt, H, 32);   hx_notc(Rt, H, 16); }
 	}
@@ -241,6 +272,11 @@ static void back_mul(int mode, float *out, size_t ldo, const float *ac, size_t l
 			} else if (mode == REF_FP32_TC_NOCOR) {
 				for (unsigned k = 0; k < n; k++) acc += h16(ac[r + k * ldac]) * h16(b[k + c * ldb]);
 				if (out_half) acc = h16(acc);
+			} else if (mode == REF_FP16_TC_NOCOR) {           /* src/tsqr.cu:268-328, :658-722: half operands, half accumulator, half result */
+				for (unsigned k = 0; k < n; k++) acc += h16(ac[r + k * ldac]) * h16(b[k + c * ldb]);
+				acc = h16(acc);
+			} else if (mode == REF_FP16_NOTC) {               /* src/tsqr.cu:143-204, :591-656 with T = half: half FMA chain (assumed) */
+				for (unsigned k = 0; k < n; k++) acc = h16(fmaf(ac[r + k * ldac], b[k + c * ldb], acc));
 			} else {
 				for (unsigned k = 0; k < n; k++) acc = fmaf(ac[r + k * ldac], b[k + c * ldb], acc);
 			}
@@ -298,8 +334,10 @@ static void tsqr16(int mode, float *q, size_t ldq, float *r, size_t ldr, const f
 
 /* plain fp32 GEMMs standing in for cuBLAS default-math SGEMM (src/blockqr.cu:92-116, 230-332).  top = 1: the handle is in
  * CUBLAS_TENSOR_OP_MATH (fp32_tc_nocor, src/blockqr.cu:64-68, 209-213): inputs rounded to fp16, fp32 accumulation (assumed). */
-static int g_top = 0;
-static inline float gin(float x) { return g_top ? h16(x) : x; }
+static int g_top = 0, g_half = 0;                    /* g_half: half-typed modes -- cublasHgemm: half in, half out; fp32 accumulation and one
+                                                         * rounding of the result assumed (see the header comment) */
+static inline float gin(float x) { return (g_top || g_half) ? h16(x) : x; }
+static inline float gout(float x) { return g_half ? h16(x) : x; }
 static void gemm_tn(float *c, size_t ldc, const float *a, size_t lda, const float *b, size_t ldb,
                     size_t mm, size_t nn, size_t kk) {          /* C(mm x nn) = A^T(mm x kk) B(kk x nn) */
 	#pragma omp parallel for collapse(2) schedule(static)
@@ -307,7 +345,7 @@ static void gemm_tn(float *c, size_t ldc, const float *a, size_t lda, const floa
 		for (long i = 0; i < (long)mm; i++) {
 			float acc = 0.0f;
 			for (size_t k = 0; k < kk; k++) acc = fmaf(gin(a[k + i * lda]), gin(b[k + j * ldb]), acc);
-			c[i + j * ldc] = acc;
+			c[i + j * ldc] = gout(acc);
 		}
 }
 static void gemm_nn(float *c, size_t ldc, float alpha, const float *a, size_t lda, const float *b, size_t ldb,
@@ -317,7 +355,7 @@ static void gemm_nn(float *c, size_t ldc, float alpha, const float *a, size_t ld
 		for (size_t j = 0; j < nn; j++) {
 			float acc = 0.0f;
 			for (size_t k = 0; k < kk; k++) acc = fmaf(gin(a[i + k * lda]), gin(b[k + j * ldb]), acc);
-			c[i + j * ldc] = alpha * acc + (beta == 0.0f ? 0.0f : beta * c[i + j * ldc]);
+			c[i + j * ldc] = gout(alpha * acc + (beta == 0.0f ? 0.0f : beta * c[i + j * ldc]));
 		}
 }
 
@@ -329,8 +367,10 @@ static void gemm_nn(float *c, size_t ldc, float alpha, const float *a, size_t ld
 int ref_qr_f32(int mode, int reorth, float *q, size_t ldq, float *r, size_t ldr, float *a, size_t lda,
                size_t m, size_t n) {
 	if (n > m || m == 0 || n == 0) return 1;
-	if (mode != REF_FP32_NOTC && mode != REF_FP32_TC_COR && mode != REF_FP32_TC_NOCOR) return -1;
+	if (mode != REF_FP32_NOTC && mode != REF_FP32_TC_COR && mode != REF_FP32_TC_NOCOR && mode != REF_FP16_NOTC && mode != REF_FP16_TC_NOCOR) return -1;
 	g_top = (mode == REF_FP32_TC_NOCOR);             /* (one factorisation at a time: the oracle is not re-entrant) */
+	g_half = (mode == REF_FP16_NOTC || mode == REF_FP16_TC_NOCOR);
+	/* half-typed modes: a, q, r are float arrays HOLDING half values (the caller rounds a; everything written is rounded here) */
 	const size_t nb = 16;
 	float *wq = (float *)malloc(sizeof(float) * ref_working_q_size(m, n));
 	float *wr = (float *)malloc(sizeof(float) * ref_working_r_size(m, n));

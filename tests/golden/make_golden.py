@@ -2,7 +2,8 @@
 """Generates tests/golden/*.npz + golden.json.
 
 The reference (enp1s0/tsqr-gpu) cannot be built or run in this image and ships no vectors, so these fixtures
-hold: the seeded input, |R| (sign-normalised) from the oracle restatement for the three restated modes, |R| from LAPACK in
+hold: the seeded input, |R| (sign-normalised) from the oracle restatement for the five restated modes (the two half-typed ones on
+the fp16 rounding of the same input), |R| from LAPACK in
 fp64 (numpy), and residual / orthogonality bands.  They pin the oracle (and the input generator) against drift;
 they are not reference output.  Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -22,11 +23,13 @@ for (m, n, seed) in [(128, 16, 0), (9211, 51, 0), (4096, 64, 0)]:
     a = ro.uniform_matrix(m, n, seed=seed)
     out = {"a_head": np.asarray(a[:8, :4]).copy()}
     resmax, orthmax = {}, {}
-    for name, md in (("fp32_notc", ro.FP32_NOTC), ("fp32_tc_cor", ro.FP32_TC_COR), ("fp32_tc_nocor", ro.FP32_TC_NOCOR)):
+    for name, md in (("fp32_notc", ro.FP32_NOTC), ("fp32_tc_cor", ro.FP32_TC_COR), ("fp32_tc_nocor", ro.FP32_TC_NOCOR),
+                     ("fp16_notc", ro.FP16_NOTC), ("fp16_tc_nocor", ro.FP16_TC_NOCOR)):
         st, q, r = ro.qr(a, md, False)
         assert st == 0
         out["absr_" + name] = np.abs(np.triu(r)).astype(np.float32)
-        resmax[name] = float(3 * ro.residual(a, q, r))
+        ain = a.astype(np.float16).astype(np.float32) if name.startswith("fp16") else a     # (io type half: the input those modes see)
+        resmax[name] = float(3 * ro.residual(ain, q, r))
         orthmax[name] = float(3 * ro.orthogonality_fro(q))
     out["absr_lapack64"] = np.abs(np.linalg.qr(a.astype(np.float64), mode="r")).astype(np.float32)
     fn = "uniform_%dx%d_seed%d.npz" % (m, n, seed)
