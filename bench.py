@@ -137,6 +137,8 @@ WORKLOADS = {
     "c2": dict(m=1 << 20, n=64, mode="fp32_tc_cor", reorth=0, input="uniform", cpu_rows=1 << 20),
     "c3": dict(m=1 << 20, n=128, mode="fp32_tc_cor", reorth=0, input="uniform", cpu_rows=1 << 19),
     "c5": dict(m=1 << 20, n=64, mode="fp32_tc_cor", reorth=1, input="latms_cond1e8", cpu_rows=1 << 20),
+    # not a BASELINE configuration: c2's shape through the half-typed modes (io type half, reference src/tsqr.hpp:38-39)
+    "c2h": dict(m=1 << 20, n=64, mode="fp16_tc_nocor", reorth=0, input="uniform", cpu_rows=1 << 20),
 }
 
 
@@ -148,7 +150,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="BASELINE.json configuration (see the module docstring)")
     ap.add_argument("--m", type=int, default=None, help="rows per GPU (default: the workload's)")
     ap.add_argument("--n", type=int, default=None)
-    ap.add_argument("--mode", default=None, choices=["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor"])
+    ap.add_argument("--mode", default=None, choices=["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor", "fp16_notc", "fp16_tc_nocor"])
     ap.add_argument("--reorth", type=int, default=None)
     ap.add_argument("--cpu-sample-rows", type=int, default=None)   # c2: the whole headline matrix, ~15 s of CPU work on 16 host threads
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -242,14 +244,17 @@ def main():
     mode = bq.compute_mode[args.mode]
 
     ld = m + args.ld_pad
-    d_a = make_input(args, m, n, m_glob, rank, dev)
-    d_q = torch.empty(n, ld, dtype=torch.float32, device=dev)[:, :m]
+    io_half = (not args.rehearse) and mode in bq.FP16_MODES   # the half-typed modes: fp16 in, fp16 out (one-GPU workloads)
+    assert not io_half or (world == 1 and not args.force_dist), "the fp16 I/O modes are single-GPU entry points"
+    io_dt = torch.float16 if io_half else torch.float32
+    d_a = make_input(args, m, n, m_glob, rank, dev).to(io_dt)
+    d_q = torch.empty(n, ld, dtype=io_dt, device=dev)[:, :m]
     if args.ld_pad:
-        a_pad = torch.zeros(n, ld, dtype=torch.float32, device=dev)
+        a_pad = torch.zeros(n, ld, dtype=io_dt, device=dev)
         a_pad[:, :m] = d_a
         d_a = a_pad[:, :m]
     a_keep = d_a.clone() if n > 64 else None                 # n > 64: the engine may overwrite A (it does not on the one-panel path)
-    d_r = torch.zeros(n, n, dtype=torch.float32, device=dev)
+    d_r = torch.zeros(n, n, dtype=io_dt, device=dev)
     eng = None
     if args.rehearse:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -342,10 +347,11 @@ def main():
             dom_ms, dom_launches = prof[dom]
             per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
             # algorithmic work of one launch of the dominant kernel
+            esz = 2.0 if io_half else 4.0                       # bytes per element of A and Q
             if dom == "apply":                                  # Q = A * inverse(R): read A, write Q
-                bound, alg_bytes, alg_flops = "hbm", 8.0 * m * n, 2.0 * m * n * n
+                bound, alg_bytes, alg_flops = "hbm", 2 * esz * m * n, 2.0 * m * n * n
             elif dom == "gram":                                 # G = A^T A: read A once
-                bound, alg_bytes, alg_flops = "hbm", 4.0 * m * n, 2.0 * m * n * n
+                bound, alg_bytes, alg_flops = "hbm", esz * m * n, 2.0 * m * n * n
             else:                                               # Householder fold: R factor of the local block
                 bound, alg_bytes, alg_flops = "mfma", 4.0 * m * n, f_r(m, n)
             if bound == "hbm":
@@ -369,7 +375,7 @@ def main():
         inp = "U(-1,1)" if args.input == "uniform" else "latms cond 1e8 (src/test_cond.cu:31-50 spectrum, seed 5)"
         out = {"metric": "tsqr_gflops", "value": gflops, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32",
+               "vs_baseline": None, "dtype": ("f16 in / out, f32 accumulation" if io_half else "f32"),
                "data": "synthetic",
                "config": {"workload": "%s: M=2^%d x N=%d per GPU, %s, reorth=%d, %s; global %d x %d; F_QR=4MN^2-4/3N^3; R-factor engine: %s" % (
                    args.workload, int(np.log2(m)) if m & (m - 1) == 0 else -1, n, args.mode, args.reorth, inp, m_glob, n, engine_name),
@@ -385,7 +391,7 @@ def main():
         if first_ms is not None:
             out["first_window"] = {"ms_per_step": first_ms, "value": flops / (first_ms * 1e-3) / 1e9, "unit": "GFLOP/s",
                                    "note": "the same W + K window taken at process start, inside the GPU's clock / power transient after idle"}
-        if world == 1 and not args.no_cpu_baseline and not args.rehearse:
+        if world == 1 and not args.no_cpu_baseline and not args.rehearse and not io_half:
             out["cpu_baseline"] = cpu_baseline(n, args.mode, args.cpu_sample_rows)
         print(json.dumps(out))
     if dist.is_initialized():

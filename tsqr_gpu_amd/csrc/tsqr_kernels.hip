@@ -1572,6 +1572,7 @@ struct ApplyArgs {
 	double* gpart;                      // GRAMQ only: per-workgroup partial Gram tiles of the OUTPUT block rows (format of gram_bf16_kernel)
 	const unsigned* skip_status;        // optional: the kernel returns at once when *skip_status != 0 (the Cholesky kernel
 	                                    // rejected its Gram matrix: a speculatively enqueued apply then costs a launch, not a pass)
+	const float* r32; void* r16; size_t ldr16;   // fp16 I/O only, optional: workgroup 0 also rounds the n x n factor r32 (ld n) to the caller's half-typed R
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1670,6 +1671,13 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	// (the verdict word is looked at only now: its round trip runs under the loads just issued; a skipped launch has merely
 	// requested a block or two of an input that is valid either way)
 	if (a.skip_status && a.skip_status[0] != 0) return;  // uniform over the grid
+	if constexpr (sizeof(IO) == 2) {
+		// (the half-typed R of the fp16 I/O modes: 4096 values -- a launch of its own costs 4.8 us, here it rides along)
+		if (blockIdx.x == 0 && a.r16) {
+			_Float16* r16 = reinterpret_cast<_Float16*>(a.r16);
+			for (int e = threadIdx.x; e < a.n * a.n; e += 64 * NW) r16[(size_t)(e / a.n) * a.ldr16 + (e % a.n)] = (_Float16)a.r32[e];
+		}
+	}
 
 	if constexpr (ENGINE == 0) {
 		float* Zs = reinterpret_cast<float*>(zbase);

@@ -627,7 +627,8 @@ template <int E> int dispatch_apply_nt(Ctx& c, int NT, const tsqrmi::ApplyArgs& 
 // q = a * inverse(r); n <= 64; Z in wq[L.z] (computed here from r unless z_ready)
 // io_half: a and q hold halves (fp16 I/O modes; engines 1 and 2)
 int apply_rinv(Ctx& c, int engine, float* q, size_t ldq, const float* a, size_t lda, const float* r, size_t ldr,
-               size_t m, size_t n, bool z_ready = false, const unsigned* skip_status = nullptr, bool io_half = false) {
+               size_t m, size_t n, bool z_ready = false, const unsigned* skip_status = nullptr, bool io_half = false,
+               void* r16 = nullptr, size_t ldr16 = 0) {
 	const size_t NP = np_of(n);
 	const int NT = (int)(NP / 16);
 	float* z_buf = c.wq + c.L.z;
@@ -638,6 +639,7 @@ int apply_rinv(Ctx& c, int engine, float* q, size_t ldq, const float* a, size_t 
 	HIPCHK(hipGetLastError());
 	tsqrmi::ApplyArgs aa{};
 	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = z_buf; aa.skip_status = skip_status;
+	aa.r32 = r; aa.r16 = r16; aa.ldr16 = ldr16;         // (io_half with r16: r is then a packed n x n factor, ld n)
 	int rc;
 	{
 		ProfScope ps(KC_APPLY, c.st);
@@ -1222,14 +1224,10 @@ int tsqr_mi_qr_f16(int mode, int reorth, void* q, size_t ldq, void* r, size_t ld
 		c.slot = 0; c.prev_slot = -1;
 		int rc = gram_g(c, reinterpret_cast<const float*>(a), lda, m, n, /*bf16=*/true, /*io_half=*/true);
 		if (!rc) rc = chol_from_g(c, r32, n, n, 2);
-		if (!rc) {
-			// (R to fp16 by its own small launch, in front of the apply pass: scattered 2-byte stores inside the Cholesky kernel cost it 5 us)
-			hipLaunchKernelGGL(tsqrmi::narrow_f16_kernel, dim3((unsigned)cdiv(cdiv(n, 8) * n, 256)), dim3(256), 0, st, reinterpret_cast<_Float16*>(r), ldr, r32, n,
-			                   n, (int)n, aligned16(r, ldr) ? 1 : 0);
-			HIPCHK(hipGetLastError());
-			rc = apply_rinv(c, engine_of(f16_engine_mode(mode)), reinterpret_cast<float*>(q), ldq, reinterpret_cast<const float*>(a), lda,
-			                r32, n, m, n, /*z_ready=*/true, c.status_dev(0), /*io_half=*/true);
-		}
+		// (R to fp16: workgroup 0 of the apply pass does it -- scattered 2-byte stores inside the Cholesky kernel cost that 5 us, a
+		// launch of its own 4.8 us)
+		if (!rc) rc = apply_rinv(c, engine_of(f16_engine_mode(mode)), reinterpret_cast<float*>(q), ldq, reinterpret_cast<const float*>(a), lda,
+		                         r32, n, m, n, /*z_ready=*/true, c.status_dev(0), /*io_half=*/true, r, ldr);
 		if (rc) return rc;
 		unsigned status = 1u;
 		float scond = 0.0f;
