@@ -1067,8 +1067,12 @@ __global__ __launch_bounds__(256, 2) void gram_blk_kernel(const GramArgs a) {
 // independent accumulators, then the 16 s-sums of every entry are added through LDS in a fixed pairwise tree.
 // gout[nelem] receives `rows` (the local row count as a double): a row-partitioned run all-reduces nelem + 1 doubles, and the
 // Cholesky kernel then reads the GLOBAL row count for its thresholds from the same payload -- every rank takes the same verdict.
+// Coupling tiles (S = Qb^T Ap of a panel pair, 16 tiles): with fin_zneg != nullptr the summed entry also leaves in its final forms --
+// -S as the 64 x 64 operand of the update pass (zero beyond column fin_ny) and S as the block of R -- what cross_finish_kernel does
+// in a launch of its own when an all-reduce sits between the sum and its use (row-partitioned runs).
 __global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ gout, const double* __restrict__ part, int nparts, int nelem,
-                                                           double rows) {
+                                                           double rows, float* __restrict__ fin_r = nullptr, size_t fin_ldr = 0,
+                                                           float* __restrict__ fin_zneg = nullptr, int fin_ny = 0) {
 	if (blockIdx.x == 0 && threadIdx.x == 0) gout[nelem] = rows;
 	__shared__ double red[16][17];
 	const int e = threadIdx.x & 15, s = threadIdx.x >> 4;
@@ -1096,8 +1100,16 @@ __global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ 
 		double v[16];
 #pragma unroll
 		for (int k = 0; k < 16; k++) v[k] = red[k][e];
-		gout[el] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
-		           (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+		const double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+		                   (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+		gout[el] = sum;
+		if (fin_zneg) {                                  // (entry el of the tile array = row i, column j of S: cross_finish_kernel's map)
+			const int t = el >> 8, reg = (el >> 6) & 3, l = el & 63;
+			const int i = 16 * (t >> 2) + 4 * (l >> 4) + reg, j = 16 * (t & 3) + (l & 15);
+			const float f = (float)sum;
+			fin_zneg[(size_t)j * 64 + i] = (j < fin_ny) ? -f : 0.0f;
+			if (j < fin_ny) fin_r[(size_t)j * fin_ldr + i] = f;
+		}
 	}
 }
 

@@ -499,7 +499,8 @@ int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16, b
 	const int nelem = g.ntri * 256;
 	{
 		ProfScope ps(KC_CHOL, c.st);
-		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), a.part, nparts, nelem, (double)m);
+		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), a.part, nparts, nelem, (double)m,
+		                   nullptr, (size_t)0, nullptr, 0);
 	}
 	HIPCHK(hipGetLastError());
 	if (c.comm.active()) {
@@ -793,11 +794,19 @@ int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq
 			ca.nchunks = g.nch; ca.cpw = g.cpw; ca.nwaves = g.nwaves; ca.part = reinterpret_cast<double*>(c.wr);
 			hipLaunchKernelGGL(tsqrmi::cross_kernel, dim3(g.nblocks), dim3(256), 0, c.st, ca);
 			const int nelem = 16 * 256;
-			hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), ca.part, g.nblocks, nelem, (double)m);
-			HIPCHK(hipGetLastError());
-			if (c.comm.active() && c.comm.allreduce_f64(c.gsum(), (size_t)nelem, c.st)) { t_last_error = "all-reduce of the coupling tiles failed"; return -1; }
-			hipLaunchKernelGGL(tsqrmi::cross_finish_kernel, dim3(16), dim3(256), 0, c.st, r + P * ldr + B, ldr, c.wq + c.L.s, c.gsum(), (int)cc);
-			HIPCHK(hipGetLastError());
+			if (!c.comm.active()) {
+				// one GPU: the reduction writes -S (operand of the update) and the block of R itself -- one launch less per panel pair
+				hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), ca.part, g.nblocks, nelem, (double)m,
+				                   r + P * ldr + B, ldr, c.wq + c.L.s, (int)cc);
+				HIPCHK(hipGetLastError());
+			} else {
+				hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), ca.part, g.nblocks, nelem, (double)m,
+				                   nullptr, (size_t)0, nullptr, 0);
+				HIPCHK(hipGetLastError());
+				if (c.comm.allreduce_f64(c.gsum(), (size_t)nelem, c.st)) { t_last_error = "all-reduce of the coupling tiles failed"; return -1; }
+				hipLaunchKernelGGL(tsqrmi::cross_finish_kernel, dim3(16), dim3(256), 0, c.st, r + P * ldr + B, ldr, c.wq + c.L.s, c.gsum(), (int)cc);
+				HIPCHK(hipGetLastError());
+			}
 			tsqrmi::ApplyArgs ua{};
 			ua.a = q + B * ldq; ua.lda = ldq; ua.q = ap; ua.ldq = lda; ua.m = m; ua.n = (int)PW; ua.z = c.wq + c.L.s; ua.n_out = (int)cc;
 			const int rc2 = (engine == 0) ? launch_apply_any<0, 4, true>(c, ua)
@@ -872,7 +881,8 @@ int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, c
 	{
 		ProfScope ps(KC_CHOL, c.st);
 		const int nelem = 36 * 256;
-		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, gsum, reinterpret_cast<const double*>(c.wr), wgs, nelem, (double)m);
+		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, gsum, reinterpret_cast<const double*>(c.wr), wgs, nelem, (double)m,
+		                   nullptr, (size_t)0, nullptr, 0);
 		// chol(G11) -> Schur complement -> chol(G22') -> Z12 + verdict: one workgroup, one launch (chol_wide_kernel)
 		tsqrmi::CholWideArgs wa{};
 		wa.gsum = gsum; wa.r = r; wa.ldr = ldr; wa.n = (int)n; wa.zf1 = c.wq + c.L.z; wa.zf2 = zf2; wa.zw = zw;
