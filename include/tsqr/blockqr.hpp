@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include "../tsqr_mi.h"
 #include "tsqr.hpp"                             // mtk::tsqr (the reference's blockqr.hpp includes its tsqr.hpp as well)
 
@@ -213,6 +214,31 @@ inline state_t qr(
 			bf.hl,
 			stream
 			);
+}
+
+// Not in the reference: its qr() synchronises the stream itself (src/blockqr.cu:78, 122, 140), so one call's host round trip sits
+// between two calls of a loop.  submit enqueues a call's first attempt and returns; finish waits for it (and completes the fallback
+// ladder for a matrix the conditioning check rejected).  Two calls of a thread may be in flight: a loop over many matrices keeps the
+// GPU busy back to back (tsqr_mi_qr_f32_submit / _finish, include/tsqr_mi.h, for the rules).  fp32 I/O modes.
+using ticket = tsqr_mi_ticket;
+template <mtk::qr::compute_mode mode, bool Reorthogonalize>
+inline void qr_submit(
+		ticket& t,
+		float* const q_ptr, const std::size_t ldq,
+		float* const r_ptr, const std::size_t ldr,
+		float* const a_ptr, const std::size_t lda,
+		const std::size_t m, const std::size_t n,
+		buffer<mode, Reorthogonalize>& bf,
+		handle_t const stream = nullptr) {
+	static_assert(std::is_same<typename mtk::qr::get_io_type<mode>::type, float>::value, "qr_submit takes the fp32 I/O modes");
+	const int st = tsqr_mi_qr_f32_submit(static_cast<int>(mode), Reorthogonalize ? 1 : 0, q_ptr, ldq, r_ptr, ldr, a_ptr, lda, m, n,
+	                                     bf.dwq, bf.dwr, bf.dw_reorth_r, bf.dl, bf.hl, stream, &t);
+	if (st < 0) throw std::runtime_error(std::string("mtk::qr::qr_submit: ") + tsqr_mi_last_error());
+}
+inline state_t qr_finish(ticket& t) {
+	const int st = tsqr_mi_qr_f32_finish(&t);
+	if (st < 0) throw std::runtime_error(std::string("mtk::qr::qr_finish: ") + tsqr_mi_last_error());
+	return st;
 }
 }  // namespace qr
 }  // namespace mtk

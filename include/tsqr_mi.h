@@ -76,14 +76,55 @@ int tsqr_mi_qr_f32(int mode, int reorth,
                    size_t m, size_t n,
                    void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
                    void* stream);
-/* `count` back-to-back blocking calls of tsqr_mi_qr_f32 with the same arguments -- the loop of the reference's speed protocol
- * (reference src/test.cu:299-309) on this side of the ABI, so that a host in an interpreted language times what a C++ caller's
- * loop costs.  Returns the first non-zero state. */
+/*
+ * Stream-asynchronous form of tsqr_mi_qr_f32.  The reference's mtk::qr::qr only ENQUEUES on the handle's stream and returns
+ * (reference src/blockqr.cu:395-449: kernel launches and cuBLAS calls, no synchronisation), so a caller's loop keeps the GPU busy
+ * back to back (its speed protocol, src/test.cu:299-309, is such a loop).  tsqr_mi_qr_f32 blocks, because its state includes the
+ * verdict of the conditioning check; the pair below gives the reference's overlap back:
+ *   tsqr_mi_qr_f32_submit  enqueues the call's first attempt (bf16-split Gram level: Gram pass, Cholesky + verdict, apply pass that
+ *                          skips itself on rejection, completion word) and returns;
+ *   tsqr_mi_qr_f32_finish  waits for that call, and when the verdict was "rejected" runs the rest of the ladder for it (blocking),
+ *                          exactly as tsqr_mi_qr_f32 would have; returns the call's state.
+ * Up to TWO calls of a host thread are in flight (their verdict words alternate between the two halves of h_wl); a third submit
+ * first waits for the oldest one's verdict.  Calls that have no speculative first attempt (reorth, n > 128, policy != auto,
+ * profiling on, h_wl not pinned) are executed inside submit, blocking; finish then just returns their state.
+ * Rules: a ticket lives until it is finished, by the thread that submitted it, tickets are finished in submission order; the
+ * arguments (A, Q, R, work buffers) stay valid and unmodified by the host until then.  Two calls in flight may share the work
+ * buffers (everything runs in stream order) -- but not Q, R or (n > 64) A if the results of both are wanted.
+ * Any other entry point of this library called by the thread meanwhile first waits for the verdicts of its tickets in flight.
+ */
+typedef struct tsqr_mi_ticket {
+	int state;                      /* the call's state, valid after finish (or after a submit that ran the call itself) */
+	int pending;                    /* 0 done, 1 first attempt in flight, 2 verdict read (ladder not yet run) */
+	int slot;                       /* which half of the pinned words the attempt reports to */
+	int own_flag;                   /* 1: a completion kernel of its own follows the attempt (always, for tsqr_mi_qr_f32_submit) */
+	unsigned seq;                   /* sequence number its completion word will show */
+	unsigned verdict;               /* 0 accepted / 1 rejected */
+	float scond;                    /* scaled conditioning S the Cholesky kernel reported */
+	int mode, reorth;
+	float *q, *r, *a;
+	size_t ldq, ldr, lda, m, n;
+	void *wq, *wr, *stream;
+	unsigned *h_wl, *words, *words_dev;   /* caller's pinned words; the pinned words actually used (host / device address) */
+} tsqr_mi_ticket;
+int tsqr_mi_qr_f32_submit(int mode, int reorth,
+                          float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                          size_t m, size_t n,
+                          void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
+                          void* stream, tsqr_mi_ticket* ticket);
+int tsqr_mi_qr_f32_finish(tsqr_mi_ticket* ticket);
+
+/* `count` calls of tsqr_mi_qr_f32 with the same arguments -- the loop of the reference's speed protocol (reference
+ * src/test.cu:299-309) on this side of the ABI, so that a host in an interpreted language times what a C++ caller's loop costs.
+ * Like the reference's loop it keeps the stream fed: call i + 1 is submitted before call i is finished (submit / finish above,
+ * two in flight); every call runs all of its kernels and every verdict is looked at.  tsqr_mi_set_loop_depth(1) makes it a loop of
+ * plain blocking calls (the latency of one call rather than the throughput of a stream of them).  Returns the first non-zero state. */
 int tsqr_mi_qr_f32_loop(int count, int mode, int reorth,
                         float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                         size_t m, size_t n,
                         void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
                         void* stream);
+void tsqr_mi_set_loop_depth(int depth);   /* 1: blocking calls, 2 (default): two calls in flight */
 
 /*
  * The fp16 I/O modes: replaces mtk::qr::qr<fp16_notc | fp16_tc_nocor, Reorthogonalize> (reference src/blockqr.cu:437-449; io type

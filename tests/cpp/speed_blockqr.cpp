@@ -1,5 +1,6 @@
 // The reference's speed protocol (src/test.cu:257-343: one warm-up call, then wall clock over C = 16 blocking calls) from a C++
-// caller of include/tsqr/blockqr.hpp -- no Python, no torch: what a user of the reference sees after switching.
+// caller of include/tsqr/blockqr.hpp -- no Python, no torch: what a user of the reference sees after switching.  The first mode is
+// also timed as a stream of calls, two in flight (qr_submit / qr_finish).
 // Prints the reference's speed CSV line plus the algorithmic TFLOP/s (F_QR = 4MN^2 - 4/3 N^3).
 #include <chrono>
 #include <cstdio>
@@ -8,7 +9,7 @@
 #include <tsqr/blockqr.hpp>
 
 template <mtk::qr::compute_mode mode, bool reorth>
-int speed(const std::size_t M, const std::size_t N, const unsigned C, const char* mode_name) {
+int speed(const std::size_t M, const std::size_t N, const unsigned C, const char* mode_name, const bool stream_of_calls = false) {
 	std::vector<float> h_a(M * N);
 	unsigned long long s = 88172645463325252ull;                     // xorshift64: U(-1,1)
 	for (auto& v : h_a) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (float)((double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0); }
@@ -28,6 +29,19 @@ int speed(const std::size_t M, const std::size_t N, const unsigned C, const char
 	const double el = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-9 / C;
 	const double fqr = 4.0 * M * N * N - 4.0 / 3.0 * N * N * N;
 	std::printf("%zu,%zu,1,float,%s,%d,%e,%e,%zu\n", M, N, mode_name, (int)reorth, el, fqr / el / 1e12, buffer.get_device_memory_size());
+	if (stream_of_calls) {
+		// the same C calls as a stream: call c + 1 is submitted before call c is finished (mtk::qr::qr_submit / qr_finish)
+		mtk::qr::ticket tk[2];
+		const auto t2 = std::chrono::system_clock::now();
+		mtk::qr::qr_submit<mode, reorth>(tk[0], d_q, M, d_r, N, d_a, M, M, N, buffer, stream);
+		for (unsigned c = 0; c < C; c++) {
+			if (c + 1 < C) mtk::qr::qr_submit<mode, reorth>(tk[(c + 1) & 1], d_q, M, d_r, N, d_a, M, M, N, buffer, stream);
+			if (mtk::qr::qr_finish(tk[c & 1]) != mtk::qr::success_factorization) return 1;
+		}
+		const auto t3 = std::chrono::system_clock::now();
+		const double el2 = std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count() * 1e-9 / C;
+		std::printf("%zu,%zu,1,float,%s/two_in_flight,%d,%e,%e,%zu\n", M, N, mode_name, (int)reorth, el2, fqr / el2 / 1e12, buffer.get_device_memory_size());
+	}
 	(void)hipFree(d_a); (void)hipFree(d_q); (void)hipFree(d_r); (void)hipStreamDestroy(stream);
 	return 0;
 }
@@ -38,7 +52,7 @@ int main(int argc, char** argv) {
 	const unsigned C = argc > 3 ? (unsigned)std::atoi(argv[3]) : 16;
 	std::printf("m,n,rand_range,type,compute_mode,reorthogonalization,elapsed_time,tflops_fqr,working_memory_size\n");
 	int rc = 0;
-	rc |= speed<mtk::qr::fp32_tc_cor, false>(M, N, C, "fp32_tc_cor");
+	rc |= speed<mtk::qr::fp32_tc_cor, false>(M, N, C, "fp32_tc_cor", /*stream_of_calls=*/true);
 	rc |= speed<mtk::qr::fp32_notc, false>(M, N, C, "fp32_notc");
 	rc |= speed<mtk::qr::fp32_tc_cor, true>(M, N, C, "fp32_tc_cor");
 	return rc;

@@ -1,0 +1,213 @@
+"""GPU tests of the stream-asynchronous entry (tsqr_mi_qr_f32_submit / _finish, include/tsqr_mi.h) and of the loop entry built on it.
+
+A submitted call is the blocking call cut in two: the same kernels in the same order on the same stream, so every result below is
+compared BIT FOR BIT with tsqr_mi_qr_f32 on the same input -- accepted matrices, matrices the conditioning check rejects (the
+ladder then runs inside finish), the n <= 16 second sweep, the 128-column one-panel path, and calls without a speculative first
+attempt (executed inside submit)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+class Problem:
+    """device copies of one matrix, its outputs and (optionally its own) work buffer"""
+
+    def __init__(self, bq, torch, a, mode, reorth=False, bf=None):
+        self.m, self.n = a.shape
+        self.a_host = np.ascontiguousarray(a.T)
+        self.d_a = torch.from_numpy(self.a_host.copy()).cuda()
+        self.d_q = torch.full((self.n, self.m), float("nan"), dtype=torch.float32, device="cuda")
+        self.d_r = torch.zeros(self.n, self.n, dtype=torch.float32, device="cuda")
+        self.mode, self.reorth = mode, reorth
+        if bf is None:
+            bf = bq.buffer(mode, reorth)
+            bf.allocate(self.m, self.n)
+        self.bf = bf
+
+    def args(self):
+        return (self.d_q, self.m, self.d_r, self.n, self.d_a, self.m, self.m, self.n, self.bf)
+
+    def result(self):
+        return self.d_q.cpu().numpy().copy(), self.d_r.cpu().numpy().copy()
+
+
+def blocking(bq, torch, a, mode, reorth=False):
+    p = Problem(bq, torch, a, mode, reorth)
+    st = bq.qr(*p.args())
+    return (st, bq.last_engine()) + p.result()
+
+
+def same(res, want):
+    return np.array_equal(res[0], want[2], equal_nan=True) and np.array_equal(res[1], want[3], equal_nan=True)
+
+
+@pytest.mark.parametrize("mode", ["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor"])
+@pytest.mark.parametrize("m,n", [(20000, 64), (9211, 51), (65536, 64), (4096, 33)])
+def test_two_calls_in_flight_share_a_buffer(bq, oracle, torch_cuda, m, n, mode):
+    md = bq.compute_mode[mode]
+    a1, a2 = oracle.uniform_matrix(m, n, seed=1), oracle.uniform_matrix(m, n, seed=2)
+    w1, w2 = blocking(bq, torch_cuda, a1, md), blocking(bq, torch_cuda, a2, md)
+    p1 = Problem(bq, torch_cuda, a1, md)
+    p2 = Problem(bq, torch_cuda, a2, md, bf=p1.bf)                      # one work buffer for both calls (stream order)
+    t1 = bq.submit(*p1.args())
+    t2 = bq.submit(*p2.args())
+    assert t1.pending == 1 and t2.pending == 1 and t1.slot != t2.slot
+    assert bq.finish(t1) == 0 and bq.last_engine() == 3
+    assert bq.finish(t2) == 0
+    assert bq.finish(t2) == 0                                            # finishing twice returns the state again
+    assert same(p1.result(), w1) and same(p2.result(), w2)
+    assert np.array_equal(p1.d_a.cpu().numpy(), p1.a_host)               # A untouched
+
+
+def test_rejected_matrix_between_two_accepted_ones(bq, oracle, torch_cuda):
+    """The middle call is rejected by the bf16-split level: its apply pass skipped itself, finish runs the ladder for it (fp64 Gram
+    level here) while the third call's attempt is already behind it in the stream."""
+    md = bq.compute_mode.fp32_tc_cor
+    m, n = 30000, 64
+    mats = [oracle.uniform_matrix(m, n, seed=5), oracle.matrix_with_cond(m, n, 1e5, seed=6).astype(np.float32), oracle.uniform_matrix(m, n, seed=7)]
+    want = [blocking(bq, torch_cuda, a, md) for a in mats]
+    assert want[0][1] == 3 and want[1][1] != 3 and want[2][1] == 3
+    ps = [Problem(bq, torch_cuda, mats[0], md)]
+    ps += [Problem(bq, torch_cuda, a, md, bf=ps[0].bf) for a in mats[1:]]
+    t0 = bq.submit(*ps[0].args())
+    t1 = bq.submit(*ps[1].args())
+    assert bq.finish(t0) == 0 and bq.last_engine() == 3
+    t2 = bq.submit(*ps[2].args())
+    assert bq.finish(t1) == 0 and bq.last_engine() == want[1][1] and t1.verdict == 1
+    assert t2.pending == 2                                               # its verdict was read before the ladder reused the slots
+    assert bq.finish(t2) == 0 and bq.last_engine() == 3
+    for p, w in zip(ps, want):
+        assert same(p.result(), w)
+    assert oracle.orthogonality_fro(ps[1].result()[0].T.astype(np.float64)) < 1e-2    # (cond 1e5 without reorthogonalisation: ~cond * eps)
+
+
+@pytest.mark.parametrize("cond", [1e7, 1e9, 1e12])
+def test_every_rung_of_the_ladder(bq, oracle, torch_cuda, cond):
+    md = bq.compute_mode.fp32_tc_cor
+    a = oracle.matrix_with_cond(20000, 64, cond, seed=9, geometric=True).astype(np.float32)
+    w = blocking(bq, torch_cuda, a, md)
+    p = Problem(bq, torch_cuda, a, md)
+    t = bq.submit(*p.args())
+    assert bq.finish(t) == 0 and bq.last_engine() == w[1] and w[1] in (1, 2, 4) and t.verdict == 1
+    assert same(p.result(), w)
+
+
+def test_narrow_panel_second_sweep(bq, oracle, torch_cuda):
+    """n <= 16: a call accepted with a scaled conditioning beyond 32 gets a second sweep -- inside finish.  (Geometric singular
+    values 1 .. 1/45: S = 55; the bf16-split level turns it down for its smallest pivot ratio, the fp64 Gram level inside finish
+    accepts it and the second sweep follows.)"""
+    md = bq.compute_mode.fp32_notc
+    a = oracle.matrix_with_cond(400000, 12, 45.0, seed=3, geometric=True).astype(np.float32)
+    w = blocking(bq, torch_cuda, a, md)
+    p = Problem(bq, torch_cuda, a, md)
+    t = bq.submit(*p.args())
+    assert bq.finish(t) == 0 and bq.last_engine() == w[1]
+    assert same(p.result(), w)
+    assert oracle.orthogonality_fro(p.result()[0].T.astype(np.float64)) < 5e-6
+
+
+def test_one_panel_of_128_columns(bq, oracle, torch_cuda):
+    md = bq.compute_mode.fp32_tc_cor
+    m, n = 30000, 128
+    a1, a2 = oracle.uniform_matrix(m, n, seed=1), oracle.matrix_with_cond(m, n, 1e7, seed=2).astype(np.float32)
+    w1, w2 = blocking(bq, torch_cuda, a1, md), blocking(bq, torch_cuda, a2, md)
+    assert w1[1] == 5 and w2[1] != 5
+    p1 = Problem(bq, torch_cuda, a1, md)
+    p2 = Problem(bq, torch_cuda, a2, md, bf=p1.bf)
+    t1 = bq.submit(*p1.args())
+    t2 = bq.submit(*p2.args())
+    assert bq.finish(t1) == 0 and bq.last_engine() == 5
+    assert bq.finish(t2) == 0 and bq.last_engine() == w2[1]            # rejected as one panel: 64-column panels inside finish
+    assert same(p1.result(), w1) and same(p2.result(), w2)
+
+
+@pytest.mark.parametrize("m,n,reorth", [(9000, 64, True), (5000, 200, False), (4096, 128, True)])
+def test_calls_without_a_speculative_attempt_run_inside_submit(bq, oracle, torch_cuda, m, n, reorth):
+    md = bq.compute_mode.fp32_tc_cor
+    a = oracle.uniform_matrix(m, n, seed=4)
+    w = blocking(bq, torch_cuda, a, md, reorth)
+    p = Problem(bq, torch_cuda, a, md, reorth)
+    t = bq.submit(*p.args())
+    assert t.pending == 0 and t.state == 0
+    assert bq.finish(t) == 0
+    assert same(p.result(), w)
+
+
+def test_third_submit_and_blocking_call_with_tickets_in_flight(bq, oracle, torch_cuda):
+    md = bq.compute_mode.fp32_tc_cor
+    m, n = 40000, 64
+    mats = [oracle.uniform_matrix(m, n, seed=s) for s in (11, 12, 13, 14)]
+    want = [blocking(bq, torch_cuda, a, md) for a in mats]
+    ps = [Problem(bq, torch_cuda, a, md) for a in mats]                 # own buffers
+    t0, t1 = bq.submit(*ps[0].args()), bq.submit(*ps[1].args())
+    t2 = bq.submit(*ps[2].args())                                        # takes t0's slot: t0's verdict is read first
+    assert t0.pending == 2 and t1.pending == 1 and t2.slot == t0.slot
+    assert bq.qr(*ps[3].args()) == 0                                     # a blocking call reads the verdicts of everything in flight first
+    assert t1.pending == 2 and t2.pending == 2
+    assert [bq.finish(t) for t in (t0, t1, t2)] == [0, 0, 0]
+    for p, w in zip(ps, want):
+        assert same(p.result(), w)
+
+
+def test_submit_error_paths(bq, torch_cuda):
+    torch = torch_cuda
+    bf = bq.buffer(bq.compute_mode.fp32_tc_cor, False)
+    bf.allocate(64, 64)
+    d = torch.zeros(64 * 64, dtype=torch.float32, device="cuda")
+    t = bq.submit(d, 8, d, 16, d, 8, 8, 16, bf)                          # n > m (reference src/blockqr.cu:409-411)
+    assert t.state == 1 and t.pending == 0 and bq.finish(t) == 1
+    t = bq.submit(d, 8, d, 8, d, 8, 8, 8, bf, mode=bq.compute_mode.tf32_tc_cor)
+    assert t.state == 2 and bq.finish(t) == 2
+    with pytest.raises(TypeError):
+        bq.submit(d, 8, d, 8, d, 8, 8, 8, bf, mode=bq.compute_mode.fp16_notc)
+
+
+@pytest.mark.parametrize("m,n,kind", [(1 << 17, 64, "uniform"), (30000, 64, "cond1e6"), (50000, 128, "uniform"), (400000, 12, "geo45")])
+def test_loop_entry_depths_agree(bq, oracle, torch_cuda, m, n, kind):
+    """tsqr_mi_qr_f32_loop with two calls in flight against the same loop of blocking calls: same outputs, same engine."""
+    md = bq.compute_mode.fp32_tc_cor
+    if kind == "uniform":
+        a = oracle.uniform_matrix(m, n, seed=8)
+    elif kind == "geo45":                                                # (n <= 16, accepted with S > 32: second sweep in every call)
+        a = oracle.matrix_with_cond(m, n, 45.0, seed=3, geometric=True).astype(np.float32)
+    else:
+        a = oracle.matrix_with_cond(m, n, float(kind[4:]), seed=8).astype(np.float32)
+    res = []
+    for depth in (1, 2):
+        bq.set_loop_depth(depth)
+        try:
+            p = Problem(bq, torch_cuda, a, md)
+            loop = bq.bind_loop(*p.args())
+            assert loop(5) == 0
+            res.append(p.result() + (bq.last_engine(),))
+            if n <= 64:
+                assert np.array_equal(p.d_a.cpu().numpy(), p.a_host)
+        finally:
+            bq.set_loop_depth(2)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    assert np.isfinite(res[0][0]).all()
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 8])
+@pytest.mark.parametrize("m,n", [(1 << 16, 64), (9211, 51), (20000, 128), (20000, 100)])
+def test_loop_counts(bq, oracle, torch_cuda, m, n, count):
+    """Inside the loop a call's completion word is raised by the first kernel of the call behind it (every Gram kernel form: block
+    pattern, chunked, 128-column fast and general), the last call by a completion kernel of its own: any count ends complete."""
+    md = bq.compute_mode.fp32_tc_cor
+    a = oracle.uniform_matrix(m, n, seed=21)
+    w = blocking(bq, torch_cuda, a, md)
+    p = Problem(bq, torch_cuda, a, md)
+    loop = bq.bind_loop(*p.args())
+    assert loop(count) == 0 and bq.last_engine() == w[1]
+    assert same(p.result(), w)
+    p.d_q.fill_(float("nan"))
+    assert loop(count) == 0                                              # and again on the same buffers (sequence numbers move on)
+    assert same(p.result(), w)

@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, heights, n, mode, reorth, policy, cond, out):
+def _worker(rank, world, port, heights, n, mode, reorth, policy, cond, loop, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -35,7 +35,10 @@ def _worker(rank, world, port, heights, n, mode, reorth, policy, cond, out):
     d_q = torch.empty(n, m_local, device="cuda"); d_r = torch.zeros(n, n, device="cuda")
     bq.set_policy(policy)
     drv = tdist.RowPartitionedQR(bq.compute_mode[mode], m_local, n, comm="callbacks")
-    st = drv.qr(d_q, m_local, d_r, d_a, m_local, reorthogonalize=reorth)
+    if loop:                                                  # `loop` calls from the C loop (tsqr_mi_qr_f32_dist_cb_loop: two calls in flight)
+        st = drv.bind_loop(d_q, m_local, d_r, d_a, m_local, reorthogonalize=reorth)(loop)
+    else:
+        st = drv.qr(d_q, m_local, d_r, d_a, m_local, reorthogonalize=reorth)
     torch.cuda.synchronize()
     a_untouched = bool(torch.equal(keep, d_a))
     r = d_r.cpu()
@@ -60,14 +63,14 @@ def _free_port():
     return p
 
 
-def _run(heights, n, mode="fp32_tc_cor", reorth=False, policy=0, cond=1.0):
+def _run(heights, n, mode="fp32_tc_cor", reorth=False, policy=0, cond=1.0, loop=0):
     import queue
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
     world = len(heights)                                      # (at most 4 here: the GPU box allows 6 processes on its card)
-    procs = [ctx.Process(target=_guarded, args=(r, world, port, heights, n, mode, reorth, policy, cond, out)) for r in range(world)]
+    procs = [ctx.Process(target=_guarded, args=(r, world, port, heights, n, mode, reorth, policy, cond, loop, out)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -185,3 +188,17 @@ def test_two_ranks_ill_conditioned_escalates_identically(oracle):
     assert np.abs(np.tril(r, -1)).max() == 0.0
     assert np.linalg.norm(q @ r - a) / np.linalg.norm(a) < 2e-6
     assert np.linalg.norm(q.T @ q - np.eye(64)) < 1e-5
+
+
+@pytest.mark.parametrize("heights,cond,loop", [((30000, 17777), 1.0, 3), ((30000, 17777), 1.0, 4), ((30000, 1, 7777, 12345), 1.0, 3),
+                                               ((40000, 25000), 1e5, 3), ((40000, 25000), 1e9, 2)])
+def test_stream_of_row_partitioned_calls(oracle, heights, cond, loop):
+    """The C loop entry with two calls in flight on every rank: call i + 1 (Gram pass, all-reduce, Cholesky, apply) is enqueued before
+    the verdict of call i is read; a rejected matrix (cond 1e5: fp64 Gram level, 1e9: shifted Cholesky QR) takes the ladder inside the
+    loop on all ranks alike -- same engine, same R, same results as a single call."""
+    one = _run(heights, 64, cond=cond)
+    res = _run(heights, 64, cond=cond, loop=loop)
+    assert res["st"] == 0 and res["r_same"] and res["a_untouched"] and res["engines"] == one["engines"]
+    assert np.array_equal(res["r"], one["r"]) and np.array_equal(res["q"], one["q"])
+    if cond == 1.0:
+        _check(res, oracle)

@@ -12,7 +12,8 @@ run() { n=$1; shift; timeout -k 10 400 python bench.py "$@" > gpurun_out/verify_
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d.get("roofline") or {}
-print("%-8s %.4f ms (first window %s)  %.1f TF/s  orth %.2e res %.2e  dominant %s %.1f us frac %.2f  | %s" % (sys.argv[2], d["ms_per_step"],
+print("%-8s %.4f ms (blocking calls %s, first window %s)  %.1f TF/s  orth %.2e res %.2e  dominant %s %.1f us frac %.2f  | %s" % (sys.argv[2], d["ms_per_step"],
+      "%.4f" % d["blocking_calls"]["ms_per_step"] if "blocking_calls" in d else "-",
       "%.4f" % d["first_window"]["ms_per_step"] if "first_window" in d else "-", d["value"] / 1e3, d["orth_fro"], d["residual"],
       r.get("kernel"), r.get("avg_launch_us", 0), r.get("frac", 0), d["config"]["engine"]))
 PY

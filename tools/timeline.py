@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-call timeline from a rocprofv3 --kernel-trace CSV of tools/loop_run.py: median duration of every kernel of a call and the median
-gaps between them (end of one kernel -> start of the next, including the gap from the completion-flag kernel of call i to the
-first kernel of call i+1).  usage: timeline.py <dir with *kernel_trace.csv> [skip_calls] [out.txt]"""
+gaps between them (end of one kernel -> start of the next, including the gap from the last kernel of call i to the first kernel of
+call i+1).  usage: timeline.py <dir with *kernel_trace.csv> [skip_calls] [out.txt] [flags]"""
 import csv, glob, statistics as st, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
@@ -10,9 +10,13 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("tsqrmi::", "")))
 rows.sort()
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-# a call ends with host_flag_kernel
+# a call ends with host_flag_kernel -- or, inside tsqr_mi_qr_f32_loop's stream of calls (two in flight, the completion word of call i
+# raised by the first kernel of call i + 1), where a Gram / fold kernel follows an apply kernel.  argv[4] = "flags": flag kernels only.
+flags_only = len(sys.argv) > 4 and sys.argv[4] == "flags"
 calls, cur = [], []
 for r in rows:
+    if cur and not flags_only and cur[-1][2].startswith("apply_") and r[2].startswith(("gram_", "fold_kernel")):
+        calls.append(cur); cur = []
     cur.append(r)
     if r[2].startswith("host_flag"):
         calls.append(cur); cur = []

@@ -47,7 +47,22 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist", "tsqr_mi_qr_f32_dist_cb",
     "tsqr_mi_qr_f32_loop", "tsqr_mi_qr_f32_dist_fn", "tsqr_mi_qr_f32_dist_fn_loop", "tsqr_mi_qr_f32_dist_cb_loop",
     "tsqr_mi_qr_f16", "tsqr_mi_qr_f16_loop", "tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16",
+    "tsqr_mi_qr_f32_submit", "tsqr_mi_qr_f32_finish", "tsqr_mi_set_loop_depth",
 ]
+
+
+class Ticket(ctypes.Structure):
+    """tsqr_mi_ticket (include/tsqr_mi.h): one call in flight between submit() and finish()."""
+    _fields_ = [("state", ctypes.c_int), ("pending", ctypes.c_int), ("slot", ctypes.c_int), ("own_flag", ctypes.c_int), ("seq", ctypes.c_uint),
+                ("verdict", ctypes.c_uint), ("scond", ctypes.c_float), ("mode", ctypes.c_int), ("reorth", ctypes.c_int),
+                ("q", ctypes.c_void_p), ("r", ctypes.c_void_p), ("a", ctypes.c_void_p),
+                ("ldq", ctypes.c_size_t), ("ldr", ctypes.c_size_t), ("lda", ctypes.c_size_t), ("m", ctypes.c_size_t), ("n", ctypes.c_size_t),
+                ("wq", ctypes.c_void_p), ("wr", ctypes.c_void_p), ("stream", ctypes.c_void_p),
+                ("h_wl", ctypes.c_void_p), ("words", ctypes.c_void_p), ("words_dev", ctypes.c_void_p)]
+
+    def __del__(self):                    # the library holds the address of a ticket in flight: never let one go away unfinished
+        if self.pending == 1 and _lib is not None:
+            _lib.tsqr_mi_qr_f32_finish(ctypes.byref(self))
 FP16_MODES = (compute_mode.fp16_notc, compute_mode.fp16_tc_nocor)     # io type half in the reference (src/tsqr.hpp:38-39)
 
 _lib = None
@@ -102,6 +117,12 @@ def lib():
     L.tsqr_mi_qr_f32_dist_cb.argtypes = [ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, ci, vp]
     L.tsqr_mi_qr_f32_loop.restype = ci
     L.tsqr_mi_qr_f32_loop.argtypes = [ci] + L.tsqr_mi_qr_f32.argtypes
+    L.tsqr_mi_qr_f32_submit.restype = ci
+    L.tsqr_mi_qr_f32_submit.argtypes = L.tsqr_mi_qr_f32.argtypes + [ctypes.POINTER(Ticket)]
+    L.tsqr_mi_qr_f32_finish.restype = ci
+    L.tsqr_mi_qr_f32_finish.argtypes = [ctypes.POINTER(Ticket)]
+    L.tsqr_mi_set_loop_depth.restype = None
+    L.tsqr_mi_set_loop_depth.argtypes = [ci]
     L.tsqr_mi_qr_f16.restype = ci
     L.tsqr_mi_qr_f16.argtypes = L.tsqr_mi_qr_f32.argtypes
     L.tsqr_mi_qr_f16_loop.restype = ci
@@ -231,6 +252,38 @@ def qr(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize
     return st
 
 
+def submit(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
+    """Stream-asynchronous qr() (tsqr_mi_qr_f32_submit): enqueues the call's first attempt and returns a ticket; finish(ticket) waits,
+    completes the ladder for a rejected matrix and returns state_t.  Up to two calls of a thread are in flight; tickets are finished in
+    submission order by the submitting thread.  fp32 I/O modes."""
+    import torch
+    mode = bf.mode if mode is None else compute_mode(mode)
+    reorth = bf.reorthogonalize if reorthogonalize is None else bool(reorthogonalize)
+    if mode in FP16_MODES:
+        raise TypeError("submit() takes the fp32 I/O modes")
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    t = Ticket()
+    t._keep = (q, r, a, bf, stream)
+    st = lib().tsqr_mi_qr_f32_submit(int(mode), int(reorth), _ptr(q), ldq, _ptr(r), ldr, _ptr(a), lda, m, n,
+                                     _ptr(bf.dwq), _ptr(bf.dwr), _ptr(bf.dw_reorth_r), _ptr(bf.dl), _ptr(bf.hl), stream.cuda_stream, ctypes.byref(t))
+    if st < 0:
+        raise RuntimeError("tsqr_mi_qr_f32_submit failed: %s" % last_error())
+    return t
+
+
+def finish(ticket):
+    st = lib().tsqr_mi_qr_f32_finish(ctypes.byref(ticket))
+    if st < 0:
+        raise RuntimeError("tsqr_mi_qr_f32_finish failed: %s" % last_error())
+    return st
+
+
+def set_loop_depth(depth):
+    """Calls in flight inside the loop entries (bind_loop): 2 (default) or 1 = plain blocking calls."""
+    lib().tsqr_mi_set_loop_depth(int(depth))
+
+
 def bind(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
     """qr() with every argument marshalled once: returns a zero-argument callable that issues exactly one C-ABI call
     (tsqr_mi_qr_f32) per invocation -- what a C++ caller's loop looks like, without per-call Python/ctypes conversions.
@@ -256,8 +309,9 @@ def bind(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonali
 
 
 def bind_loop(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
-    """Like bind(), but the callable takes a count k and issues k back-to-back blocking calls from ONE C loop (tsqr_mi_qr_f32_loop):
-    the reference's speed protocol (src/test.cu:299-309) without interpreter time between the calls."""
+    """Like bind(), but the callable takes a count k and issues k calls from ONE C loop (tsqr_mi_qr_f32_loop): the reference's speed
+    protocol (src/test.cu:299-309) without interpreter time between the calls.  The fp32 loop keeps two calls in flight (submit /
+    finish) unless set_loop_depth(1)."""
     import torch
     mode = bf.mode if mode is None else compute_mode(mode)
     reorth = bf.reorthogonalize if reorthogonalize is None else bool(reorthogonalize)

@@ -640,12 +640,21 @@ struct GramArgs {
 	double* part;                        // [gridDim.x][NTRI][256]  (tile, lane, reg) order of the MFMA accumulators
 	const unsigned* skip_status;         // optional: return at once when *skip_status != 0 (an earlier, speculatively enqueued
 	                                     // sweep this pass depends on was rejected; its successor Cholesky reports "rejected" too)
+	unsigned* announce; unsigned announce_seq;   // optional: completion word (pinned host memory) of the CALL IN FRONT of this one in the
+	                                     // stream and the value to raise it to
 };
+
+// A stream of calls (tsqr_mi_qr_f32_loop): the first kernel of call i + 1 starts when the last kernel of call i has finished (stream
+// order), so it can raise call i's completion word itself -- a one-thread kernel (4 us of launch ramp) less per call.
+__device__ __forceinline__ void announce_previous_call(unsigned* word, unsigned seq) {
+	if (word && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(word) = seq;
+}
 
 template <int NT>
 __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
+	announce_previous_call(a.announce, a.announce_seq);
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
@@ -722,6 +731,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
+	announce_previous_call(a.announce, a.announce_seq);
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
@@ -939,6 +949,7 @@ __global__ __launch_bounds__(256, 2) void gram_blk_kernel(const GramArgs a) {
 	constexpr int NTRI = 10;
 	extern __shared__ __attribute__((aligned(16))) float gb_as[];        // [buffer][column][GB_RS]
 	static_assert(GB_LDS_BYTES >= (int)sizeof(double) * 2 * NTRI * 256, "the final workgroup reduction aliases the block buffers");
+	announce_previous_call(a.announce, a.announce_seq);
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

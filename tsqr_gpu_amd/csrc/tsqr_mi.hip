@@ -46,6 +46,7 @@ struct Settings {
 	std::atomic<int> level0_waves{2048}, tree_cpw{4}, gram_waves{2048};
 	std::atomic<int> wide{1};            // 64 < n <= 128: one Cholesky-QR panel of up to 128 columns first (policy 5 turns it off)
 	std::atomic<int> apply_wgs{0};       // workgroups of the apply pass; 0: as many as are resident at once (tsqr_mi_set_tuning2)
+	std::atomic<int> loop_depth{2};      // calls in flight inside the *_loop entries (tsqr_mi_set_loop_depth)
 	// the two environment switches that are left (read once at load): the floor of the bf16-split level's bound on the scaled
 	// conditioning S, and a diagnostic print of every Cholesky verdict
 	const float bf16_scond_floor = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);
@@ -256,6 +257,11 @@ struct Ctx {
 	bool gramq_ready = false;                            // the next bf16-level Gram request can skip its pass (partials are in place)
 	Comm comm;
 	bool fold_cor = false;                               // Householder engine: block reflectors on the error-corrected bf16x3 MFMA (fp32_tc_cor)
+	bool resume_accepted = false;                        // tsqr_mi_qr_f32_finish: the first attempt ran already and was accepted with
+	float resume_scond = 0.0f;                           // this scaled conditioning (only the n <= 16 second sweep is left to do)
+	int start_level = -1;                                // tsqr_mi_qr_f32_finish: the ladder resumes at this level (the ones above were rejected)
+	unsigned* announce_word = nullptr;                   // completion word of the call in front of this one, raised by this call's first
+	unsigned announce_seq = 0;                           // Gram kernel (consumed by the launch that carries it)
 	double rows_global = 0.0;                            // host's view of the global row count (the device thresholds of a row-partitioned
 	                                                     // call use the all-reduced count instead)
 	unsigned* status_dev(int s) const { return reinterpret_cast<unsigned*>(wq + L.status) + 16 * s; }
@@ -323,6 +329,39 @@ int wait_done(Ctx& c) {
 	const int w = signal_and_wait(c);
 	if (w < 0) return w;
 	if (w == 1) HIPCHK(hipStreamSynchronize(c.st));
+	return 0;
+}
+
+// ---- calls in flight (tsqr_mi_qr_f32_submit / _finish): at most two per host thread, one per half of the pinned words (status
+// words 4 * slot .. 4 * slot + 2, completion word 4 * slot + 3).  "Latching" a ticket = waiting for its completion word and copying
+// the verdict out of the pinned words, after which the slot (and the stream behind it) is free for anything else. ----
+thread_local tsqr_mi_ticket* t_pending[2] = {nullptr, nullptr};
+thread_local unsigned t_submits = 0;
+int ticket_latch(tsqr_mi_ticket* t) {
+	if (!t || t->pending != 1) return 0;
+	volatile unsigned* w = reinterpret_cast<volatile unsigned*>(t->words) + 4 * t->slot;
+	hipStream_t st = reinterpret_cast<hipStream_t>(t->stream);
+	for (bool done = false; !done;) {
+		for (int i = 0; i < 20000 && !done; i++) {
+			done = (w[3] == t->seq);
+			if (!done) __builtin_ia32_pause();
+		}
+		if (!done) {                                     // (a failed launch must not hang the caller: look at the stream now and then)
+			const hipError_t e = hipStreamQuery(st);
+			if (e == hipSuccess) done = true;
+			else if (e != hipErrorNotReady) { t_pending[t->slot] = nullptr; t->pending = 0; t->state = -1; HIPCHK(e); }
+		}
+	}
+	t->verdict = w[0];
+	const unsigned b = w[2];
+	memcpy(&t->scond, &b, 4);
+	t->pending = 2;
+	if (t_pending[t->slot] == t) t_pending[t->slot] = nullptr;
+	return 0;
+}
+int latch_all() {
+	for (int s = 0; s < 2; s++)
+		if (t_pending[s]) { const int rc = ticket_latch(t_pending[s]); if (rc) return rc; }
 	return 0;
 }
 
@@ -460,6 +499,7 @@ int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16, b
 	a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
 	a.part = reinterpret_cast<double*>(c.wr);
 	a.skip_status = c.prev_slot >= 0 ? c.status_dev(c.prev_slot) : nullptr;
+	if (!io_half && !(bf16 && c.gramq_ready)) { a.announce = c.announce_word; a.announce_seq = c.announce_seq; c.announce_word = nullptr; }
 	int nparts = g.nblocks;                              // workgroups that wrote a partial
 	if (bf16 && c.gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		c.gramq_ready = false;
@@ -868,9 +908,11 @@ int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, c
 			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GW_LDS_BYTES));
 			attr.done(c.dev);
 		}
+		ga.announce = c.announce_word; ga.announce_seq = c.announce_seq; c.announce_word = nullptr;   // (the first launch carries it)
 		if (wgs_fast) {
 			ga.blk0 = 0; ga.nblk = (int)nfull;
 			hipLaunchKernelGGL((tsqrmi::gram_wide_kernel<true>), dim3(wgs_fast), dim3(512), tsqrmi::GW_LDS_BYTES, c.st, ga);
+			ga.announce = nullptr;
 		}
 		if (wgs_rest) {
 			ga.blk0 = (int)nfull; ga.nblk = (int)nrest; ga.part += (size_t)wgs_fast * 36 * 256;
@@ -929,7 +971,7 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 	// speculatively and steps down when chol16_kernel rejected it; with check_now panel_qr escalates per panel by itself.
 	const int first_level = !use_gram ? 0 : c.gram_level;
 	bool wide_done = false;
-	if (c.wide && n > PW && n <= 2 * PW && may_fall_back && first_level == 2 && !c.comm.active()) {
+	if (c.wide && n > PW && n <= 2 * PW && may_fall_back && first_level == 2 && !c.comm.active() && !c.resume_accepted) {
 		// one Cholesky-QR panel over all n columns; rejected (ill conditioned) -> the 64-column panel path below, A is still intact
 		float* r1 = c.wq + L.r1; float* r2 = c.wq + L.r2;
 		unsigned st = 1u;
@@ -955,7 +997,8 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 		}
 		wide_done = (st == 0);
 	}
-	for (int level = first_level; level >= 0 && !wide_done; level--) {
+	if (c.resume_accepted) scond1 = c.resume_scond;
+	for (int level = (c.start_level >= 0 ? std::min(c.start_level, first_level) : first_level); level >= 0 && !wide_done && !c.resume_accepted; level--) {
 		int rc;
 		if (!reorth) {
 			// level 0 reached in the speculative (deferred) mode: both Gram levels were rejected and the fp64 Gram matrix of A is
@@ -1054,7 +1097,10 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 	return TSQR_MI_SUCCESS;
 }
 
-void init_ctx(Ctx& c, void* wq, void* wr, size_t m_layout, size_t n, void* stream) {
+void init_ctx(Ctx& c, void* wq, void* wr, size_t m_layout, size_t n, void* stream, bool keep_in_flight = false) {
+	// every entry point starts here: calls of this thread still in flight (submit without finish) have their verdicts read first --
+	// what follows may reuse their pinned words and status slots
+	if (!keep_in_flight) (void)latch_all();
 	c.st = reinterpret_cast<hipStream_t>(stream);
 	c.dev = cur_device();
 	c.wq = reinterpret_cast<float*>(wq);
@@ -1175,15 +1221,142 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 	return qr_core(c, engine, reorth, q, ldq, r, ldr, a, lda, m, n);
 }
 
-// `count` back-to-back blocking calls with the same arguments: the reference's speed protocol (src/test.cu:299-309 is such a C++ loop
-// around the blocking call).  Returns the first non-zero state.
-int tsqr_mi_qr_f32_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
-                        size_t m, size_t n, void* wq_v, void* wr_v, float* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
+// ---- submit / finish: the first attempt of a call (bf16-split Gram level, everything speculative) is enqueued and the host returns;
+// finish reads the verdict and, for a rejected matrix, runs the rest of the ladder as the blocking call does (include/tsqr_mi.h) ----
+// own_flag: a one-thread completion kernel behind the attempt (the public entry: always).  The loop entry leaves it out for every call
+// but the last and lets the NEXT call's first kernel raise the word instead (`announce`: the ticket submitted just before this one).
+// CallEnv: what a row-partitioned call adds to the arguments (its collectives); env.dist == false: the single-GPU call.
+struct CallEnv { bool dist = false; Comm comm; int nranks = 1; };
+static void env_ctx(Ctx& c, const CallEnv& env, void* wq_v, void* wr_v, size_t m, size_t n, unsigned* h_wl, void* stream, bool keep_in_flight) {
+	if (env.dist) {                                      // (as qr_dist_common)
+		c.comm = env.comm;
+		init_ctx(c, wq_v, wr_v, std::max(m, (size_t)env.nranks * std::min(n, PW)), n, stream, keep_in_flight);
+		c.comm.nranks = env.nranks;
+		c.rows_global = (double)m * (double)env.nranks;
+		resolve_host_sig(c, nullptr, m);
+	} else {
+		init_ctx(c, wq_v, wr_v, m, n, stream, keep_in_flight);
+		c.rows_global = (double)m;
+		resolve_host_sig(c, h_wl, m);
+	}
+}
+static int submit_impl(const CallEnv& env, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                       size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream, tsqr_mi_ticket* t,
+                       tsqr_mi_ticket* announce, bool own_flag) {
+	if (!t) return TSQR_MI_ERROR_INVALID_SIZE;
+	*t = tsqr_mi_ticket{};
+	t->mode = mode; t->reorth = reorth; t->q = q; t->r = r; t->a = a; t->ldq = ldq; t->ldr = ldr; t->lda = lda; t->m = m; t->n = n;
+	t->wq = wq_v; t->wr = wr_v; t->stream = stream; t->h_wl = h_wl;
+	if ((!env.dist && n > m) || m == 0 || n == 0 || env.nranks < 1) return t->state = TSQR_MI_ERROR_INVALID_SIZE;
+	const int engine = engine_of(mode);
+	if (engine < 0) { t_last_error = "compute_mode not implemented on gfx950"; return t->state = TSQR_MI_ERROR_UNSUPPORTED; }
+	Ctx c;
+	env_ctx(c, env, wq_v, wr_v, m, n, h_wl, stream, /*keep_in_flight=*/true);
+	const bool narrow = n <= PW, wide = c.wide && n > PW && n <= 2 * PW && !env.dist;
+	if (!(c.policy == 0 && c.gram_level == 2 && !reorth && (narrow || wide) && c.hsig.dev && !t_prof.on && !g_set.debug)) {
+		// no speculative first attempt for this call: run it here (finish returns its state)
+		const int rc = latch_all();
+		return t->state = rc ? rc : qr_core(c, engine, reorth, q, ldq, r, ldr, a, lda, m, n);
+	}
+	const int slot = (int)(t_submits++ & 1u);
+	if (t_pending[slot]) { const int rc = ticket_latch(t_pending[slot]); if (rc) return t->state = rc; }
+	c.fold_cor = (engine == 1);
+	c.min_level = 2;
+	c.slot = slot; c.prev_slot = -1;
+	if (announce && announce->pending == 1 && !announce->own_flag) {
+		if (announce->words == c.hsig.host && announce->stream == stream) {
+			c.announce_word = c.hsig.dev + 4 * announce->slot + 3;
+			c.announce_seq = announce->seq;
+		} else {                                         // other pinned words or another stream: a completion kernel of its own after all
+			hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(announce->stream),
+			                   announce->words_dev + 4 * announce->slot + 3, announce->seq);
+			(void)hipGetLastError();
+		}
+	}
+	const int rc = narrow ? sweep(c, engine, 2, /*check_now=*/false, q, ldq, r, ldr, a, lda, m, n) : sweep_wide(c, engine, q, ldq, r, ldr, a, lda, m, n);
+	if (rc) return t->state = rc;
+	if (c.announce_word) {                               // (no kernel of the attempt carried the announcement: raise the word here)
+		hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, c.announce_word, c.announce_seq);
+		(void)hipGetLastError();
+	}
+	unsigned seq = ++g_seq;
+	if (seq == 0) seq = ++g_seq;
+	reinterpret_cast<volatile unsigned*>(c.hsig.host)[4 * slot + 3] = 0;
+	if (own_flag) {
+		hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, c.hsig.dev + 4 * slot + 3, seq);
+		if (hipGetLastError() != hipSuccess) {           // the attempt is enqueued but cannot announce itself: drain and run the call
+			HIPCHK(hipStreamSynchronize(c.st));
+			return t->state = qr_core(c, engine, reorth, q, ldq, r, ldr, a, lda, m, n);
+		}
+	}
+	t->slot = slot; t->seq = seq; t->words = c.hsig.host; t->words_dev = c.hsig.dev; t->own_flag = own_flag ? 1 : 0; t->pending = 1;
+	t_pending[slot] = t;
+	return TSQR_MI_SUCCESS;
+}
+int tsqr_mi_qr_f32_submit(int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                          size_t m, size_t n, void* wq_v, void* wr_v, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
+                          void* stream, tsqr_mi_ticket* t) {
+	(void)reorth_w; (void)d_wl;
+	return submit_impl(CallEnv{}, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream, t, nullptr, /*own_flag=*/true);
+}
+
+static int finish_impl(const CallEnv& env, tsqr_mi_ticket* t) {
+	if (!t) return TSQR_MI_ERROR_INVALID_SIZE;
+	if (t->pending == 0) return t->state;
+	if (t->pending == 1) { const int rc = ticket_latch(t); if (rc) { t->pending = 0; return t->state = rc; } }
+	t->pending = 0;
+	const bool wide = t->n > PW;
+	if (t->verdict == 0 && !(t->n <= 16 && t->scond > 32.0f)) {
+		t_last_engine = wide ? 5 : 3;                    // accepted at the bf16-split Gram level: Q and R are in place
+		return t->state = TSQR_MI_SUCCESS;
+	}
+	// rejected (or the n <= 16 second sweep is due): the blocking path from here on; calls submitted after this one have run their
+	// attempts by the time anything below executes (stream order) and init_ctx reads their verdicts before their slots are reused
+	Ctx c;
+	env_ctx(c, env, t->wq, t->wr, t->m, t->n, t->h_wl, t->stream, /*keep_in_flight=*/false);
+	if (t->verdict == 0) { c.resume_accepted = true; c.resume_scond = t->scond; }
+	else if (wide) c.wide = false;                       // the one-panel attempt was rejected: 64-column panels (A is intact)
+	else c.start_level = 1;                              // the bf16-split level was rejected: the ladder resumes at the fp64 Gram level
+	return t->state = qr_core(c, engine_of(t->mode), t->reorth, t->q, t->ldq, t->r, t->ldr, t->a, t->lda, t->m, t->n);
+}
+int tsqr_mi_qr_f32_finish(tsqr_mi_ticket* t) { return finish_impl(CallEnv{}, t); }
+
+// `count` calls with the same arguments as a stream: call i + 1 is submitted before call i is finished; the completion word of call i
+// is raised by the first kernel of call i + 1 (stream order: it starts when call i has finished), only the last call carries a
+// completion kernel of its own.  Row-partitioned calls: every rank takes the same verdicts (they come from the all-reduced Gram
+// matrix), hence the same path through this loop and the same order of collectives.
+static int stream_of_calls(const CallEnv& env, int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                           size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
+	tsqr_mi_ticket tk[2];
+	int st = submit_impl(env, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream, &tk[0], nullptr, /*own_flag=*/count == 1);
+	if (st) return st;
 	for (int i = 0; i < count; i++) {
-		const int st = tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
-		if (st) return st;
+		tsqr_mi_ticket* cur = &tk[i & 1];
+		tsqr_mi_ticket* nxt = (i + 1 < count) ? &tk[(i + 1) & 1] : nullptr;
+		if (nxt) {
+			st = submit_impl(env, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream, nxt, cur, /*own_flag=*/i + 2 == count);
+			if (st) { (void)finish_impl(env, cur); return st; }
+		}
+		st = finish_impl(env, cur);
+		if (st) { if (nxt) (void)finish_impl(env, nxt); return st; }
 	}
 	return TSQR_MI_SUCCESS;
+}
+
+void tsqr_mi_set_loop_depth(int depth) { g_set.loop_depth = depth < 2 ? 1 : 2; }
+
+// `count` calls with the same arguments: the reference's speed protocol (src/test.cu:299-309 is such a C++ loop around its call).
+// Two calls in flight (submit i + 1, then finish i) unless tsqr_mi_set_loop_depth(1).  Returns the first non-zero state.
+int tsqr_mi_qr_f32_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                        size_t m, size_t n, void* wq_v, void* wr_v, float* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
+	if (count < 2 || g_set.loop_depth.load() < 2) {
+		for (int i = 0; i < count; i++) {
+			const int st = tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
+			if (st) return st;
+		}
+		return TSQR_MI_SUCCESS;
+	}
+	return stream_of_calls(CallEnv{}, count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
 }
 
 // ---- fp16 I/O modes: reference mtk::qr::qr<fp16_notc | fp16_tc_nocor, Reorthogonalize> (src/blockqr.cu:437-449; io and working
@@ -1309,21 +1482,37 @@ int tsqr_mi_qr_f32_dist_cb(int mode, int reorth, float* q, size_t ldq, float* r,
 int tsqr_mi_qr_f32_dist_fn_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                                 size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
                                 void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream) {
-	for (int i = 0; i < count; i++) {
-		const int st = tsqr_mi_qr_f32_dist_fn(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, nccl_comm,
-		                                      nccl_allreduce_fn, nccl_allgather_fn, nranks, stream);
-		if (st) return st;
+	if (count < 2 || g_set.loop_depth.load() < 2 || !nccl_comm || !nccl_allreduce_fn || !nccl_allgather_fn) {
+		for (int i = 0; i < count; i++) {
+			const int st = tsqr_mi_qr_f32_dist_fn(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, nccl_comm,
+			                                      nccl_allreduce_fn, nccl_allgather_fn, nranks, stream);
+			if (st) return st;
+		}
+		return TSQR_MI_SUCCESS;
 	}
-	return TSQR_MI_SUCCESS;
+	CallEnv env;
+	env.dist = true; env.nranks = nranks;
+	env.comm.nccl = nccl_comm;
+	env.comm.nccl_allreduce = reinterpret_cast<nccl_allreduce_t>(nccl_allreduce_fn);
+	env.comm.nccl_allgather = reinterpret_cast<nccl_allgather_t>(nccl_allgather_fn);
+	env.comm.gather_buf = gather_buf;
+	return stream_of_calls(env, count, mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, nullptr, stream);
 }
 int tsqr_mi_qr_f32_dist_cb_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                                 size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
                                 tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream) {
-	for (int i = 0; i < count; i++) {
-		const int st = tsqr_mi_qr_f32_dist_cb(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, allreduce, allgather, user, nranks, stream);
-		if (st) return st;
+	if (count < 2 || g_set.loop_depth.load() < 2 || !allreduce || !allgather) {
+		for (int i = 0; i < count; i++) {
+			const int st = tsqr_mi_qr_f32_dist_cb(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, allreduce, allgather, user, nranks, stream);
+			if (st) return st;
+		}
+		return TSQR_MI_SUCCESS;
 	}
-	return TSQR_MI_SUCCESS;
+	CallEnv env;
+	env.dist = true; env.nranks = nranks;
+	env.comm.cb_allreduce = allreduce; env.comm.cb_allgather = allgather; env.comm.cb_user = user;
+	env.comm.gather_buf = gather_buf;
+	return stream_of_calls(env, count, mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, nullptr, stream);
 }
 
 // ---- staged entry points (building blocks; every call builds its own context) ----

@@ -19,6 +19,7 @@ struct GramWideArgs {
 	int blk0, nblk;                      // this launch covers the 64-row blocks blk0 .. blk0 + nblk - 1
 	double* part;                        // [gridDim.x][36][256] doubles, tile order of wide_tile() below
 	const unsigned* skip_status;
+	unsigned* announce; unsigned announce_seq;   // as in GramArgs: completion word of the call in front of this one
 };
 
 // destination tile of the pair (ti, tj), ti <= tj, in the summed array: [G11: 10 tiles, NT = 4 order][G22: 10 tiles][G12: 16 tiles row-major]
@@ -118,6 +119,7 @@ constexpr int GW_LDS_BYTES = 2 * 3 * 128 * GW_CS * 4;
 template <bool FAST>
 __global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned gw_img[];    // [buffer][image hi / mid / lo][column][row pair]
+	announce_previous_call(a.announce, a.announce_seq);
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the per-role MFMA sections are scalar branches
