@@ -345,7 +345,7 @@ def main():
         try:
             blocking_ms = timed_window()
         finally:
-            bq.set_loop_depth(2)
+            bq.set_loop_depth(3)
     flops = f_qr(m_glob, n)
     gflops = flops / (ms_per_step * 1e-3) / 1e9
 

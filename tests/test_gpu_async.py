@@ -170,7 +170,7 @@ def test_submit_error_paths(bq, torch_cuda):
         bq.submit(d, 8, d, 8, d, 8, 8, 8, bf, mode=bq.compute_mode.fp16_notc)
 
 
-@pytest.mark.parametrize("m,n,kind", [(1 << 17, 64, "uniform"), (30000, 64, "cond1e6"), (50000, 128, "uniform"), (400000, 12, "geo45")])
+@pytest.mark.parametrize("m,n,kind", [(1 << 17, 64, "uniform"), (1 << 15, 64, "cond1e6"), (30000, 64, "cond1e6"), (50000, 128, "uniform"), (400000, 12, "geo45")])
 def test_loop_entry_depths_agree(bq, oracle, torch_cuda, m, n, kind):
     """tsqr_mi_qr_f32_loop with two calls in flight against the same loop of blocking calls: same outputs, same engine."""
     md = bq.compute_mode.fp32_tc_cor
@@ -181,7 +181,7 @@ def test_loop_entry_depths_agree(bq, oracle, torch_cuda, m, n, kind):
     else:
         a = oracle.matrix_with_cond(m, n, float(kind[4:]), seed=8).astype(np.float32)
     res = []
-    for depth in (1, 2):
+    for depth in (1, 2, 3):                                              # (3: also the chained schedule for 2^k x 64)
         bq.set_loop_depth(depth)
         try:
             p = Problem(bq, torch_cuda, a, md)
@@ -191,8 +191,9 @@ def test_loop_entry_depths_agree(bq, oracle, torch_cuda, m, n, kind):
             if n <= 64:
                 assert np.array_equal(p.d_a.cpu().numpy(), p.a_host)
         finally:
-            bq.set_loop_depth(2)
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+            bq.set_loop_depth(3)
+    for k in (1, 2):
+        assert np.array_equal(res[0][0], res[k][0]) and np.array_equal(res[0][1], res[k][1]) and res[0][2] == res[k][2]
     assert np.isfinite(res[0][0]).all()
 
 
@@ -211,3 +212,33 @@ def test_loop_counts(bq, oracle, torch_cuda, m, n, count):
     p.d_q.fill_(float("nan"))
     assert loop(count) == 0                                              # and again on the same buffers (sequence numbers move on)
     assert same(p.result(), w)
+
+
+@pytest.mark.parametrize("mode", ["fp32_tc_cor", "fp32_notc", "fp32_tc_nocor"])
+@pytest.mark.parametrize("m,pad,count", [(128, 0, 3), (384, 4, 5), (4096, 0, 4), (65536, 8, 3), (1 << 20, 0, 6)])
+def test_chained_schedule_shapes(bq, oracle, torch_cuda, m, pad, count, mode):
+    """Full 64-column matrices of 128 k rows up to 2^20 take the chained schedule (the R-factor chain of call i inside the Gram launch
+    of call i + 1): one block to 8192 blocks, padded leading dimensions, every apply engine -- the results of the blocking call."""
+    torch = torch_cuda
+    md = bq.compute_mode[mode]
+    a = oracle.uniform_matrix(m, 64, seed=31)
+    ld = m + pad
+    buf = np.zeros((64, ld), np.float32); buf[:, :m] = a.T
+    res = []
+    for depth in (1, 3):
+        d_a = torch.from_numpy(buf).cuda()
+        d_q = torch.full((64, ld), float("nan"), dtype=torch.float32, device="cuda")
+        d_r = torch.zeros(64, 64, dtype=torch.float32, device="cuda")
+        bf = bq.buffer(md, False); bf.allocate(m, 64)
+        bq.set_loop_depth(depth)
+        try:
+            assert bq.bind_loop(d_q, ld, d_r, 64, d_a, ld, m, 64, bf)(count) == 0 and bq.last_engine() == 3
+        finally:
+            bq.set_loop_depth(3)
+        qh = d_q.cpu().numpy()
+        assert np.isnan(qh[:, m:]).all() and np.array_equal(d_a.cpu().numpy(), buf)
+        res.append((qh[:, :m].copy(), d_r.cpu().numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    if mode != "fp32_tc_nocor":                                          # (uncorrected fp16 products: 1e-3 by construction)
+        q = res[1][0].T.astype(np.float64)
+        assert oracle.orthogonality_fro(q) < 5e-6 and oracle.residual(a, q, res[1][1].T.astype(np.float64)) < 5e-6

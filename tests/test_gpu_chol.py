@@ -139,3 +139,37 @@ def test_timing_report(st):
         ms = run(st, g[:n, :n], n, level=2, reps=50)[5]
         print("%s n=%d: %.2f us per launch (back to back; diagnostic build with time stamps)" % ("chol16_kernel", n, ms * 1e3))
     assert ms < 0.05
+
+
+@pytest.mark.parametrize("m,kind", [(1 << 16, "uniform"), (1 << 20, "uniform"), (8192, "uniform"), (1 << 16, "cond30"), (1 << 16, "dependent")])
+def test_chained_launch_against_the_launches_it_merges(st, m, kind):
+    """gram_blk_chain_kernel (tsqr_mi_qr_f32_loop's chained schedule): its chain role -- 160 reduction workgroups, the last adder factors
+    on four waves -- against gram_reduce1_kernel + chol16_kernel on the same partials, its Gram role against gram_blk_kernel; twice in
+    a row (the ticket is re-armed by the last adder)."""
+    L, torch = st
+    L.tsqr_selftest_chain.restype = ctypes.c_int
+    L.tsqr_selftest_chain.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    a = torch.rand(64, m, generator=g, device="cuda") * 2 - 1
+    if kind == "cond30":                                                  # rejected by the bf16-split level: same verdict words
+        a = a * torch.logspace(0, -1.5, 64, device="cuda")[:, None] + a[:1] * 3.0
+    elif kind == "dependent":
+        a[7] = a[3]
+    nparts = min(m // 128, 512)
+    r3 = torch.full((3, 64, 64), float("nan"), device="cuda")
+    z3 = torch.full((3, 64, 64), float("nan"), device="cuda")
+    st3 = torch.full((3, 16), 77, dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(2 * nparts * 2560 + 2 * 2568 + 2, dtype=torch.float64, device="cuda")
+    eq = ctypes.c_int(-1)
+    rc = L.tsqr_selftest_chain(a.data_ptr(), m, m, nparts, r3.data_ptr(), z3.data_ptr(), st3.data_ptr(), scratch.data_ptr(), ctypes.byref(eq))
+    assert rc == 0 and eq.value == 1                                      # Gram role: the partials of gram_blk_kernel, bit for bit
+    r3, z3, st3 = r3.cpu().numpy(), z3.cpu().numpy(), st3.cpu().numpy()
+    assert np.array_equal(st3[0, :1], st3[1, :1]) and np.array_equal(st3[1, :3], st3[2, :3])
+    assert np.array_equal(r3[1], r3[2], equal_nan=True) and np.array_equal(z3[1], z3[2], equal_nan=True)
+    if kind != "dependent":
+        # same reduction order, same elimination order: four waves and sixteen agree to the last bit on finite data
+        assert np.array_equal(r3[0], r3[1]) and np.array_equal(z3[0], z3[1])
+        assert np.array_equal(st3[0, :2], st3[1, :2])
+        assert abs(float(st3[0, 2:3].view(np.float32)[0]) - float(st3[1, 2:3].view(np.float32)[0])) <= 1e-5 * abs(float(st3[0, 2:3].view(np.float32)[0]))
+    assert st3[0, 0] == (0 if kind == "uniform" else 1)

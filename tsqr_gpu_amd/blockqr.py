@@ -280,7 +280,8 @@ def finish(ticket):
 
 
 def set_loop_depth(depth):
-    """Calls in flight inside the loop entries (bind_loop): 2 (default) or 1 = plain blocking calls."""
+    """The loop entries (bind_loop): 1 = plain blocking calls, 2 = two calls in flight, 3 (default) = also the chained schedule for full
+    64-column matrices of up to 2^20 rows (the R-factor chain of call i inside the Gram launch of call i + 1)."""
     lib().tsqr_mi_set_loop_depth(int(depth))
 
 

@@ -1,6 +1,8 @@
 // selftest.hip -- GPU unit tests of the wave-level primitives and MFMA operand layouts used by tsqr_kernels.hip.
 // Built into libtsqr_selftest.so; driven by tests/test_gpu_primitives.py.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <vector>
 #include "tsqr_kernels.hip"
 
 namespace {
@@ -79,6 +81,47 @@ extern "C" float tsqr_selftest_chol(float* r, size_t ldr, float* z, unsigned* st
 	return reps > 0 ? ms / reps : 0.0f;
 }
 
+
+// ---- gram_blk_chain_kernel against the launches it merges (tsqr_mi_qr_f32_loop's chained schedule): m x 64 matrix a (m % 128 == 0).
+// r / z / status [0]: gram_blk_kernel -> gram_reduce1_kernel -> chol16_kernel.  [1]: chain role of a fused launch on the same partials,
+// whose Gram role writes a second set of partials; [2]: chain role of a SECOND fused launch on that second set (ticket re-armed by the
+// first).  scratch: 2 * nparts * 2560 + 2 * 2568 doubles + 2 words; part_equal <- 1 when both sets of partials are bitwise equal.
+extern "C" int tsqr_selftest_chain(const float* a, size_t lda, size_t m, int nparts, float* r3, float* z3, unsigned* status3, double* scratch, int* part_equal_host) {
+	const int nelem = 2560, nred = nelem / 16;
+	double* partA = scratch; double* partB = partA + (size_t)nparts * nelem;
+	double* gsum1 = partB + (size_t)nparts * nelem; double* gsum2 = gsum1 + 2568;
+	unsigned* ticket = reinterpret_cast<unsigned*>(gsum2 + 2568);
+	(void)hipMemset(ticket, 0, 8);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES);
+	tsqrmi::GramArgs ga{};
+	ga.a = a; ga.lda = lda; ga.m = m; ga.n = 64; ga.nchunks = (int)(m / 128); ga.part = partA;
+	auto chol = [&](int k, double* gs) {
+		tsqrmi::CholArgs c{};
+		c.r = r3 + 4096 * k; c.ldr = 64; c.z = z3 + 4096 * k; c.status = status3 + 16 * k; c.gsum = gs; c.rows = (double)m; c.n = 64; c.NT = 4; c.level = 2;
+		c.scond_floor = 4.0f;
+		return c;
+	};
+	hipLaunchKernelGGL(tsqrmi::gram_blk_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, 0, ga);
+	hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nred), dim3(256), 0, 0, gsum1, partA, nparts, nelem, (double)m, nullptr, (size_t)0, nullptr, 0);
+	hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, 0, chol(0, gsum1));
+	tsqrmi::ChainArgs ch{};
+	ch.chol = chol(1, gsum2); ch.part = partA; ch.nparts = nparts; ch.ticket = ticket; ch.nred = nred;
+	ga.part = partB;
+	hipLaunchKernelGGL(tsqrmi::gram_blk_chain_kernel, dim3(nred + nparts), dim3(256), tsqrmi::GB_LDS_BYTES, 0, ga, ch);
+	ch.chol = chol(2, gsum2); ch.part = partB;
+	ga.part = partA;                                     // (rewrites the first set with the same values)
+	hipLaunchKernelGGL(tsqrmi::gram_blk_chain_kernel, dim3(nred + nparts), dim3(256), tsqrmi::GB_LDS_BYTES, 0, ga, ch);
+	if (hipDeviceSynchronize() != hipSuccess) return -1;
+	std::vector<double> ha((size_t)nparts * nelem), hb((size_t)nparts * nelem);
+	(void)hipMemcpy(ha.data(), partA, ha.size() * 8, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(hb.data(), partB, hb.size() * 8, hipMemcpyDeviceToHost);
+	*part_equal_host = memcmp(ha.data(), hb.data(), ha.size() * 8) == 0 ? 1 : 0;
+	unsigned t = 1;
+	(void)hipMemcpy(&t, ticket, 4, hipMemcpyDeviceToHost);
+	if (t != 0) return -2;                               // the last adder did not re-arm the ticket
+	return (int)hipGetLastError();
+}
 
 // ---- in-kernel time stamps of chol16_kernel (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----
 extern "C" int tsqr_selftest_chol_stamps(unsigned long long* out_dev, float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT,

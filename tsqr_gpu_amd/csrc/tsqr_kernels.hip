@@ -945,17 +945,17 @@ __global__ __launch_bounds__(256) void gram_h_kernel(const GramArgs a) {
 // Partials in the same format as gram_bf16_kernel.
 constexpr int GB_ROWS = 128, GB_RS = 136;
 constexpr int GB_LDS_BYTES = 2 * 64 * GB_RS * 4;
-__global__ __launch_bounds__(256, 2) void gram_blk_kernel(const GramArgs a) {
+// (the body takes its workgroup number and the number of Gram workgroups as arguments: gram_blk_chain_kernel below runs it on a part of
+// its grid)
+__device__ __forceinline__ void gram_blk_body(const GramArgs& a, float* gb_as, const int wg, const int nwg) {
 	constexpr int NTRI = 10;
-	extern __shared__ __attribute__((aligned(16))) float gb_as[];        // [buffer][column][GB_RS]
 	static_assert(GB_LDS_BYTES >= (int)sizeof(double) * 2 * NTRI * 256, "the final workgroup reduction aliases the block buffers");
-	announce_previous_call(a.announce, a.announce_seq);
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int c = lane & 15, q = lane >> 4;
 	const int lcol = lane >> 5, lrow = 4 * (lane & 31);
-	const int nblk = a.nchunks, step = gridDim.x;        // 128-row blocks (the host sends only m % 128 == 0, n == 64, 16-byte aligned columns, lda < 2^23)
+	const int nblk = a.nchunks, step = nwg;              // 128-row blocks (the host sends only m % 128 == 0, n == 64, 16-byte aligned columns, lda < 2^23)
 	f64x4 tot[NTRI];
 #pragma unroll
 	for (int t = 0; t < NTRI; t++) tot[t] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256, 2) void gram_blk_kernel(const GramArgs a) {
 	// register sets X, Y and two block buffers; the loop head sits between "stage the next block" and "barrier" (gram_wide_kernel)
 	constexpr int BUF = 64 * GB_RS;
 	f32x4 vx[8], vy[8];
-	int bi = blockIdx.x, it = 0;
+	int bi = wg, it = 0;
 	load_block(vx, bi);
 	asm volatile("" ::: "memory");
 	load_block(vy, bi + step);
@@ -1065,12 +1065,17 @@ __global__ __launch_bounds__(256, 2) void gram_blk_kernel(const GramArgs a) {
 	}
 	__syncthreads();
 	if (wv == 0) {
-		double* out = a.part + (size_t)blockIdx.x * NTRI * 256;
+		double* out = a.part + (size_t)wg * NTRI * 256;
 #pragma unroll
 		for (int t = 0; t < NTRI; t++)
 #pragma unroll
 			for (int r = 0; r < 4; r++) part_store(&out[(t * 4 + r) * 64 + lane], tot[t][r] + red[(t * 4 + r) * 64 + lane]);
 	}
+}
+__global__ __launch_bounds__(256, 2) void gram_blk_kernel(const GramArgs a) {
+	extern __shared__ __attribute__((aligned(16))) float gb_as[];        // [buffer][column][GB_RS]
+	announce_previous_call(a.announce, a.announce_seq);
+	gram_blk_body(a, gb_as, blockIdx.x, gridDim.x);
 }
 
 // gram_reduce1_kernel: partials -> G in ONE launch (deterministic: fixed partition, fixed tree).  A workgroup owns 16
@@ -1081,13 +1086,13 @@ __global__ __launch_bounds__(256, 2) void gram_blk_kernel(const GramArgs a) {
 // Coupling tiles (S = Qb^T Ap of a panel pair, 16 tiles): with fin_zneg != nullptr the summed entry also leaves in its final forms --
 // -S as the 64 x 64 operand of the update pass (zero beyond column fin_ny) and S as the block of R -- what cross_finish_kernel does
 // in a launch of its own when an all-reduce sits between the sum and its use (row-partitioned runs).
-__global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ gout, const double* __restrict__ part, int nparts, int nelem,
-                                                           double rows, float* __restrict__ fin_r = nullptr, size_t fin_ldr = 0,
-                                                           float* __restrict__ fin_zneg = nullptr, int fin_ny = 0) {
-	if (blockIdx.x == 0 && threadIdx.x == 0) gout[nelem] = rows;
-	__shared__ double red[16][17];
+template <bool WT = false>                               // WT: the sums leave as device-scope write-through stores (gram_blk_chain_kernel)
+__device__ __forceinline__ void gram_reduce1_body(const int blk, double (*red)[17], double* __restrict__ gout, const double* __restrict__ part,
+                                                  int nparts, int nelem, double rows, float* __restrict__ fin_r, size_t fin_ldr,
+                                                  float* __restrict__ fin_zneg, int fin_ny) {
+	if (blk == 0 && threadIdx.x == 0) gout[nelem] = rows;
 	const int e = threadIdx.x & 15, s = threadIdx.x >> 4;
-	const int el = blockIdx.x * 16 + e;
+	const int el = blk * 16 + e;
 	double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 	if (el < nelem) {
 		// the first 512 partials of this thread's stride: 32 loads issued back to back (one memory round trip instead of eight),
@@ -1113,7 +1118,8 @@ __global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ 
 		for (int k = 0; k < 16; k++) v[k] = red[k][e];
 		const double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
 		                   (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
-		gout[el] = sum;
+		if (WT) __hip_atomic_store(&gout[el], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else gout[el] = sum;
 		if (fin_zneg) {                                  // (entry el of the tile array = row i, column j of S: cross_finish_kernel's map)
 			const int t = el >> 8, reg = (el >> 6) & 3, l = el & 63;
 			const int i = 16 * (t >> 2) + 4 * (l >> 4) + reg, j = 16 * (t & 3) + (l & 15);
@@ -1122,6 +1128,12 @@ __global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ 
 			if (j < fin_ny) fin_r[(size_t)j * fin_ldr + i] = f;
 		}
 	}
+}
+__global__ __launch_bounds__(256) void gram_reduce1_kernel(double* __restrict__ gout, const double* __restrict__ part, int nparts, int nelem,
+                                                           double rows, float* __restrict__ fin_r = nullptr, size_t fin_ldr = 0,
+                                                           float* __restrict__ fin_zneg = nullptr, int fin_ny = 0) {
+	__shared__ double red[16][17];
+	gram_reduce1_body<false>(blockIdx.x, red, gout, part, nparts, nelem, rows, fin_r, fin_ldr, fin_zneg, fin_ny);
 }
 
 // The Cholesky step: sub-sums -> G (fp64) -> R = chol(G) and M = R^-T by the same row operations (forward elimination of
@@ -1403,6 +1415,239 @@ __global__ __launch_bounds__(1024) void chol16_kernel(const CholArgs a) {
 	}
 	chol_body16(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
 	            shift, min_diag);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same step on FOUR waves (round 2's form of it: wave w owns four consecutive rows of each 16-row block), for the one place where
+// the Cholesky step has to live in a 256-thread workgroup: gram_blk_chain_kernel.  Its LDS comes from the caller (42.5 KB).
+// ---------------------------------------------------------------------------------------------
+// Row ownership of the elimination kernels: thread (w, j) holds column j of the rows  row(w, s) = 16*(s>>2) + 4*w + (s&3),
+// i.e. every wave owns FOUR consecutive rows of each 16-row block.  A "group" = those four rows: its owner factors them
+// against each other in registers (lane broadcasts, no LDS), publishes the four finished rows, and after ONE barrier all
+// waves apply the four rank-1 updates to their remaining rows.  16 barriers for 64 rows; after the four groups of a block
+// the register rows rotate by four so the active block is always slots 0..3.
+template <int U>
+__device__ __forceinline__ void chol_group4(double (&g)[16], double (&mm)[16], double* Rrow, double* Mrow, float* __restrict__ r, size_t ldr,
+                                           float* __restrict__ z, int NP, double* Zd,
+                                           double* pv, int w, int j, int n, int kk, double dgj, double& s_acc) {
+	const int K0 = 16 * kk + 4 * U;
+	if (K0 >= n) return;                                 // uniform over the workgroup (the barrier below included)
+	double* rr = Rrow + (U & 1) * 256;                   // [4][64]
+	double* mr = Mrow + (U & 1) * 256;
+	if (w == U) {
+		// the owner's section is the critical path (three waves wait at the barrier): nothing but the pivots, the two row
+		// scalings, the in-group eliminations and the publication of the rows; fp32 copies, Z and the verdict sums are taken
+		// from the published rows by a wave that is off the path (below)
+		static_for<0, 4>([&](auto uu) {
+			constexpr int u = decltype(uu)::value;
+			const int K = K0 + u;
+			const double piv0 = bcast_lane_f64(g[u], K);
+			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
+			double y = __builtin_amdgcn_rsq(piv);
+			y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);      // one Newton step (v_rsq_f64 is good to ~2^-23: 2^-45 after it)
+			const bool live = K < n;
+			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
+			const double mk = live ? mm[u] * y : 0.0;
+			static_for<u + 1, 4>([&](auto vv) {
+				constexpr int v = decltype(vv)::value;
+				const double rkv = bcast_lane_f64(rk, K0 + v);   // R[K][K0+v]
+				g[v] = fma(-rkv, rk, g[v]);
+				mm[v] = fma(-rkv, mk, mm[v]);
+			});
+			rr[u * 64 + j] = rk;
+			mr[u * 64 + j] = mk;
+			if (j == 0 && live) pv[K] = piv0;
+		});
+	}
+	lds_barrier();                                       // (LDS only: the result stores below stay in flight across the groups)
+	double rkj[4], mkc[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) { rkj[u] = rr[u * 64 + j]; mkc[u] = mr[u * 64 + j]; }
+	if (w == ((U + 3) & 3)) {                            // the previous owner: not the next one, which is on the critical path
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int K = K0 + u;
+			if (K < n) {
+				// the finished rows leave for global memory at once (round 3: the stores overlap the rest of the elimination instead
+				// of forming a 5 K-cycle tail): column K of Z = row K of M, contiguous; row K of R, strided by ldr, exact zeros
+				// below the diagonal
+				if (j < NP) z[(size_t)K * NP + j] = (j <= K) ? (float)mkc[u] : 0.0f;     // Z[j][K] = M[K][j]
+				if (j < n) r[(size_t)j * ldr + K] = (j >= K) ? (float)rkj[u] : 0.0f;
+				Zd[K * 65 + j] = (j <= K) ? mkc[u] : 0.0;                            // (fp64 image, read on by chol_wide_kernel)
+				if (j <= K) s_acc = fma(dgj * mkc[u], mkc[u], s_acc);                // sum of g_jj * Z[j][K]^2
+			}
+		}
+	}
+	const int nlive = 16 - 4 * kk;                       // register rows that still exist
+#pragma unroll
+	for (int s = 0; s < 16; s++) {
+		if (s < nlive && !(s < 4 && w <= U)) {            // wave-uniform; slots 0..3 of waves <= U are finished rows
+			const int i = 16 * (kk + (s >> 2)) + 4 * w + (s & 3);
+			double acc_g = g[s], acc_m = mm[s];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const double rki = rr[u * 64 + i];           // R[K0+u][i]; rows i > K0+3 here
+				acc_g = fma(-rki, rkj[u], acc_g);
+				acc_m = fma(-rki, mkc[u], acc_m);
+			}
+			g[s] = acc_g; mm[s] = acc_m;
+		}
+	}
+}
+
+// LOADG: functor e -> G tile entry e (accumulator order); host_status: optional device-visible alias of pinned host memory
+// that receives the three status words as well (the host then needs no copy operation to read them).
+template <class LOADG>
+__device__ __forceinline__ void chol_body4(float* __restrict__ r, size_t ldr, float* __restrict__ z, unsigned* __restrict__ status,
+                                          unsigned* __restrict__ host_status, LOADG loadg, int n, int NT, int f32_layout, float min_ratio,
+                                          float max_scond, double shift_coef, double min_diag, double* lds) {
+	double* Gs = lds;                            // [64 * 65] symmetric G (assembly); afterwards the fp64 image of Z: Gs[K * 65 + j] = Z[j][K]
+	double* Rrow = Gs + 64 * 65;                 // [2 * 256]
+	double* Mrow = Rrow + 2 * 256;               // [2 * 256]
+	double* dg = Mrow + 2 * 256;                 // [64]
+	double* pv = dg + 64;                        // [64]
+	const int t = threadIdx.x;
+	const int j = t & 63, w = t >> 6;
+	const int NP = 16 * NT;
+	// issue the loads of G first (one value per thread and tile), then initialise LDS while they are in flight
+	double gv[10];
+	{
+		int idx = 0;
+		for (int ti = 0; ti < 4; ti++)
+			for (int tj = ti; tj < 4; tj++) {
+				if (ti < NT && tj < NT) { gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = loadg(idx * 256 + t); idx++; }
+				else gv[ti * 4 + tj - (ti * (ti + 1)) / 2] = 0.0;
+			}
+	}
+	if (NT < 4)                                          // with all ten tiles present every entry of Gs is written below
+		for (int i = t; i < 64 * 65; i += 256) Gs[i] = 0.0;
+	for (int e = n * NP + t; e < NP * NP; e += 256) z[e] = 0.0f;          // padding rows of Z
+	__syncthreads();
+	{
+		const int reg = t >> 6, l = t & 63;
+#pragma unroll
+		for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+			for (int tj = ti; tj < 4; tj++) {
+				if (ti < NT && tj < NT) {
+					// C/D layouts: f64 MFMA row = (lane>>4) + 4*reg, f32/bf16 MFMA row = 4*(lane>>4) + reg; col = lane&15
+					const int row = 16 * ti + (f32_layout ? 4 * (l >> 4) + reg : (l >> 4) + 4 * reg);
+					const int col = 16 * tj + (l & 15);
+					const double v = gv[ti * 4 + tj - (ti * (ti + 1)) / 2];
+					// a diagonal tile holds (i,j) and (j,i); in the bf16-split Gram matrix they can differ by an ulp (cross terms
+					// are added in opposite order), so only the upper-triangle owner writes both mirror positions
+					if (row <= col) {
+						Gs[row * 65 + col] = v;
+						Gs[col * 65 + row] = v;
+					}
+				}
+			}
+	}
+	__syncthreads();
+	if (shift_coef > 0.0) {
+		// shifted Cholesky (Fukaya et al., "Shifted Cholesky QR for computing the QR factorization of ill-conditioned matrices",
+		// SIAM J. Sci. Comput. 2020): G + s I with s = shift_coef * trace(G) >= 11 (mn + n(n+1)) u ||A||_2^2 is safely positive
+		// definite for any fp32 input; the caller runs a second (unshifted) sweep on the resulting Q
+		if (w == 0) {
+			double tr = (j < n) ? Gs[j * 65 + j] : 0.0;
+			for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+			if (j < n) Gs[j * 65 + j] += shift_coef * tr;
+		}
+		__syncthreads();
+	}
+	double g[16], mm[16];
+#pragma unroll
+	for (int s = 0; s < 16; s++) {
+		const int i = 16 * (s >> 2) + 4 * w + (s & 3);
+		g[s] = Gs[i * 65 + j];
+		mm[s] = (i == j) ? 1.0 : 0.0;
+	}
+	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; }
+	const double dgj = Gs[j * 65 + j];
+	double s_acc = 0.0;
+	__syncthreads();
+#pragma unroll 1
+	for (int kk = 0; kk < 4; kk++) {
+		static_for<0, 4>([&](auto u) { chol_group4<decltype(u)::value>(g, mm, Rrow, Mrow, r, ldr, z, NP, Gs, pv, w, j, n, kk, dgj, s_acc); });
+#pragma unroll
+		for (int s = 0; s < 12; s++) { g[s] = g[s + 4]; mm[s] = mm[s + 4]; }   // the next 16-row block moves to slots 0..3
+	}
+	// scaled conditioning S = || D * inverse(R) ||_F^2 / n with D = diag(sqrt(g_jj)): 1 for orthogonal columns of any scaling,
+	// ~cond^2 of the column-scaled matrix otherwise.  An entry-wise error eps*sqrt(g_ii g_jj) of G perturbs Q^T Q by <= eps*n*S.
+	for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o);
+	__syncthreads();
+	if (j == 0) Rrow[w] = s_acc;
+	__syncthreads();
+	// status[0]: 0 ok, 1 rejected: a pivot fell below min_ratio of its diagonal entry (2^-40 for the fp64 Gram matrix:
+	//            cond(A)^2 beyond fp64 Cholesky; 2^-5 for the bf16-split Gram matrix) or S exceeds max_scond (bf16-split Gram
+	//            matrix only: its fp32 accumulation is good enough for nearly orthogonal columns only)
+	// status[1]: bit pattern of the smallest pivot ratio (float), status[2]: of S (float) -- diagnostics
+	if (w == 0) {
+		const double d0 = dg[j], p0 = pv[j];
+		float ratio = (j < n) ? ((d0 > 0.0) ? (float)(p0 / d0) : 0.0f) : 1.0f;
+		// min_diag (bf16-split level): a column whose squared norm is so small that its fp32 products live near the denormal range
+		// was not accumulated accurately (measured: entries ~1e-22 gave ||Q^T Q - I|| = 1e-2) -> reject, the fp64 level is exact
+		if (j < n && !(d0 >= min_diag)) ratio = 0.0f;
+		for (int o = 32; o > 0; o >>= 1) ratio = fminf(ratio, __shfl_xor(ratio, o));
+		if (j == 0) {
+			const float scond = (float)(((Rrow[0] + Rrow[1]) + (Rrow[2] + Rrow[3])) / (double)n);
+			const unsigned s0 = (ratio > min_ratio && scond <= max_scond) ? 0u : 1u;     // NaN compares false -> rejected
+			status[0] = s0;
+			status[1] = __builtin_bit_cast(unsigned, ratio);
+			status[2] = __builtin_bit_cast(unsigned, scond);
+			if (host_status) {
+				// (no fence: the host reads these words only after the completion word of a LATER kernel on the stream, or after a
+				// stream synchronisation -- a system-scope release here wrote back the whole L2 on the critical path of every call)
+				volatile unsigned* hs = host_status;
+				hs[1] = __builtin_bit_cast(unsigned, ratio);
+				hs[2] = __builtin_bit_cast(unsigned, scond);
+				hs[0] = s0;
+			}
+		}
+	}
+	// (R and Z have left for global memory row by row during the elimination: chol_group)
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// A STREAM of 2^k x 64 calls (tsqr_mi_qr_f32_loop): the R-factor chain of call i -- reduction of its Gram partials, Cholesky, verdict;
+// 22 us during which one workgroup works and the rest of the chip idles -- runs in the shadow of the Gram pass of call i + 1, in ONE
+// launch: the first `nred` workgroups of the grid reduce 16 entries each (gram_reduce1_body: same partition, same order of additions
+// as the launch of its own) and take a ticket; the one that draws the last ticket factors (last-adder pattern: no workgroup ever
+// waits for another).  All other workgroups are the Gram pass of the next call, numbered from 0 as in gram_blk_kernel.
+// ---------------------------------------------------------------------------------------------
+struct ChainArgs {
+	CholArgs chol;                       // (level 2; chol.gsum receives the reduced matrix)
+	const double* part; int nparts;      // Gram partials of the call being factored
+	unsigned* ticket;                    // arrival counter, zero at launch; the last adder re-arms it
+	int nred;                            // reduction workgroups = entries / 16
+};
+__global__ __launch_bounds__(256, 2) void gram_blk_chain_kernel(const GramArgs a, const ChainArgs ch) {
+	extern __shared__ __attribute__((aligned(16))) float gb_as[];
+	static_assert(GB_LDS_BYTES >= (int)sizeof(double) * (64 * 65 + 4 * 256 + 128), "chol_body4's arrays alias the block buffers");
+	announce_previous_call(a.announce, a.announce_seq);
+	if ((int)blockIdx.x >= ch.nred) {
+		gram_blk_body(a, gb_as, (int)blockIdx.x - ch.nred, (int)gridDim.x - ch.nred);
+		return;
+	}
+	const CholArgs& c = ch.chol;
+	gram_reduce1_body<true>(blockIdx.x, reinterpret_cast<double (*)[17]>(gb_as), const_cast<double*>(c.gsum), ch.part, ch.nparts, 10 * 256, c.rows,
+	                        nullptr, 0, nullptr, 0);
+	// The sums left as device-scope write-through stores; once they are acknowledged (vmcnt) the workgroup takes its ticket.  No
+	// fence anywhere: a release / acquire fence here writes back / invalidates a whole L2 per wave, 640 times per launch, under the
+	// Gram pass that runs beside it (measured: the launch took 85 us instead of 49).
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	__shared__ unsigned last;
+	if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(ch.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ch.nred - 1)) ? 1u : 0u;
+	__syncthreads();
+	if (!last) return;
+	if (threadIdx.x == 0) __hip_atomic_store(ch.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+	const double rows = c.rows;
+	const float max_scond = fminf(128.0f, fmaxf(c.scond_floor, 0.12f * sqrtf((float)rows)));
+	const double* g = c.gsum;                            // (written by other workgroups of this launch: device-scope loads)
+	chol_body4(c.r, c.ldr, c.z, c.status, c.host_status, [&](int e) { return __hip_atomic_load(&g[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, c.n, c.NT, /*f32_layout=*/1, 0.03125f, max_scond, 0.0,
+	           rows * 0x1p-90, reinterpret_cast<double*>(gb_as));
 }
 
 // ---------------------------------------------------------------------------------------------

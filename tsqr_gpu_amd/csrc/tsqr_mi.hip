@@ -46,7 +46,7 @@ struct Settings {
 	std::atomic<int> level0_waves{2048}, tree_cpw{4}, gram_waves{2048};
 	std::atomic<int> wide{1};            // 64 < n <= 128: one Cholesky-QR panel of up to 128 columns first (policy 5 turns it off)
 	std::atomic<int> apply_wgs{0};       // workgroups of the apply pass; 0: as many as are resident at once (tsqr_mi_set_tuning2)
-	std::atomic<int> loop_depth{2};      // calls in flight inside the *_loop entries (tsqr_mi_set_loop_depth)
+	std::atomic<int> loop_depth{3};      // *_loop entries: 1 blocking calls, 2 two calls in flight, 3 also the chained schedule (tsqr_mi_set_loop_depth)
 	// the two environment switches that are left (read once at load): the floor of the bf16-split level's bound on the scaled
 	// conditioning S, and a diagnostic print of every Cholesky verdict
 	const float bf16_scond_floor = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);
@@ -1115,7 +1115,7 @@ size_t working_r_need(size_t m, size_t n) {
 	size_t need = 0;
 	for (size_t P = 0; P < n; P += PW) {
 		need = std::max(need, make_plan(m, std::min(PW, n - P)).stack_a);
-		need = std::max(need, gram_plan(m, std::min(PW, n - P)).part_floats);
+		need = std::max(need, (n <= PW ? 2 : 1) * gram_plan(m, std::min(PW, n - P)).part_floats);   // (n <= 64: two sets, stream_of_calls_chained)
 		if (n > PW) need = std::max(need, (size_t)gram_plan(m, PW).nblocks * 16 * 256 * 2);
 	}
 	if (n > PW && n <= 2 * PW) need = std::max(need, wide_part_floats(m));
@@ -1325,8 +1325,123 @@ int tsqr_mi_qr_f32_finish(tsqr_mi_ticket* t) { return finish_impl(CallEnv{}, t);
 // is raised by the first kernel of call i + 1 (stream order: it starts when call i has finished), only the last call carries a
 // completion kernel of its own.  Row-partitioned calls: every rank takes the same verdicts (they come from the all-reduced Gram
 // matrix), hence the same path through this loop and the same order of collectives.
+// The stream for full 64-column matrices of up to 2^20 rows (the shapes gram_blk_kernel takes): the R-factor chain of call i (reduction,
+// Cholesky, verdict) runs inside the launch that is the Gram pass of call i + 1 (gram_blk_chain_kernel), so a call costs its two
+// streaming passes and nothing else:
+//     gram(0) | [chain(0) + gram(1)]  apply(0) | [chain(1) + gram(2)]  apply(1) | ... | reduce, Cholesky (launches of their own)  apply(last)
+// Two sets of Gram partials (wr), everything else as in the plain stream: verdict words alternate, the completion word of call i is
+// raised by the first kernel behind apply(i).  Returns -2 when the shape / settings are not the ones this schedule is for (nothing
+// enqueued).  A rejected verdict (never seen by a well-conditioned loop) drains the stream and finishes the count with blocking calls.
+static int stream_of_calls_chained(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                                   size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
+	const int engine = engine_of(mode);
+	if (count < 3 || engine < 0 || reorth || n != PW || m % 128 != 0 || m > ((size_t)1 << 20) || lda % 4 != 0 || lda > ((size_t)1 << 24) ||
+	    lda < m || ldq < m || ldr < n || (reinterpret_cast<uintptr_t>(a) & 15) != 0)
+		return -2;
+	Ctx c;
+	init_ctx(c, wq_v, wr_v, m, n, stream);
+	c.rows_global = (double)m;
+	resolve_host_sig(c, h_wl, m);
+	if (!(c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug)) return -2;
+	c.fold_cor = (engine == 1);
+	static DevOnce attr;
+	if (attr.need(c.dev)) {
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES));
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES));
+		attr.done(c.dev);
+	}
+	const GramPlan g = gram_plan(m, n);
+	const int nchunks = (int)(m / 128), nparts = std::min(nchunks, g.nblocks), nelem = 10 * 256, nred = nelem / 16;
+	double* part[2] = {reinterpret_cast<double*>(c.wr), reinterpret_cast<double*>(c.wr) + (size_t)g.nblocks * nelem};
+	unsigned* ticket = c.status_dev(0) + 8;              // (a word of the status area no kernel uses)
+	HIPCHK(hipMemsetAsync(ticket, 0, sizeof(unsigned), c.st));
+	volatile unsigned* words = reinterpret_cast<volatile unsigned*>(c.hsig.host);
+	unsigned seq[2] = {0, 0};
+	unsigned* announce = nullptr; unsigned announce_seq = 0;             // completion word the next launch raises
+	auto gram_args = [&](int i) {
+		tsqrmi::GramArgs ga{};
+		ga.a = a; ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = nchunks; ga.cpw = g.cpw; ga.nwaves = g.nwaves;
+		ga.part = part[i & 1];
+		ga.announce = announce; ga.announce_seq = announce_seq; announce = nullptr;
+		return ga;
+	};
+	auto chol_args = [&](int i, float* rr, size_t ld) {
+		tsqrmi::CholArgs ca{};
+		ca.r = rr; ca.ldr = ld; ca.z = c.wq + c.L.z;
+		ca.status = c.status_dev(i & 1);
+		ca.host_status = c.hsig.dev + 4 * (i & 1);
+		ca.gsum = c.gsum();
+		ca.rows = c.rows_global;
+		ca.n = (int)n; ca.NT = 4; ca.level = 2; ca.scond_floor = g_set.bf16_scond_floor;
+		return ca;
+	};
+	// one step = the launches of call i behind its Gram pass: chain(i) (with the Gram pass of call i + 1 when there is one), apply(i)
+	auto step = [&](int i) -> int {
+		if (i + 1 < count) {
+			tsqrmi::ChainArgs ch{};
+			ch.chol = chol_args(i, r, ldr);
+			ch.part = part[i & 1]; ch.nparts = nparts; ch.ticket = ticket; ch.nred = nred;
+			hipLaunchKernelGGL(tsqrmi::gram_blk_chain_kernel, dim3(nred + nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(i + 1), ch);
+		} else {
+			// the last call: no Gram pass left to hide behind -- the chain as launches of its own (and the completion word of the call
+			// before, which no Gram kernel is there to raise)
+			if (announce) { hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, announce, announce_seq); announce = nullptr; }
+			hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nred), dim3(256), 0, c.st, c.gsum(), part[i & 1], nparts, nelem, (double)m,
+			                   nullptr, (size_t)0, nullptr, 0);
+			hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, chol_args(i, r, ldr));
+		}
+		HIPCHK(hipGetLastError());
+		c.slot = i & 1;
+		const int rc = apply_rinv(c, engine, q, ldq, a, lda, r, ldr, m, n, /*z_ready=*/true, c.status_dev(i & 1));
+		if (rc) return rc;
+		unsigned sq = ++g_seq;
+		if (sq == 0) sq = ++g_seq;
+		seq[i & 1] = sq;
+		words[4 * (i & 1) + 3] = 0;
+		if (i + 1 < count) { announce = c.hsig.dev + 4 * (i & 1) + 3; announce_seq = sq; }   // raised by the first launch of step i + 1
+		else hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, c.hsig.dev + 4 * (i & 1) + 3, sq);
+		HIPCHK(hipGetLastError());
+		return 0;
+	};
+	hipLaunchKernelGGL(tsqrmi::gram_blk_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(0));
+	HIPCHK(hipGetLastError());
+	int rc = step(0);
+	if (rc) return rc;
+	for (int i = 0; i < count; i++) {
+		if (i + 1 < count) { rc = step(i + 1); if (rc) return rc; }
+		// wait for call i (completion word; the stream is looked at now and then so that a failed launch cannot hang the caller)
+		for (bool done = false; !done;) {
+			for (int k = 0; k < 20000 && !done; k++) {
+				done = (words[4 * (i & 1) + 3] == seq[i & 1]);
+				if (!done) __builtin_ia32_pause();
+			}
+			if (!done) {
+				const hipError_t e = hipStreamQuery(c.st);
+				if (e == hipSuccess) done = true;
+				else if (e != hipErrorNotReady) HIPCHK(e);
+			}
+		}
+		if (words[4 * (i & 1)] != 0) {
+			// call i was rejected by the bf16-split level (its apply pass skipped itself): drain, then this call and the rest of the
+			// count as blocking calls with their whole ladder
+			HIPCHK(hipStreamSynchronize(c.st));
+			for (int k = i; k < count; k++) {
+				const int st = tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, nullptr, nullptr, h_wl, stream);
+				if (st) return st;
+			}
+			return TSQR_MI_SUCCESS;
+		}
+	}
+	t_last_engine = 3;
+	return TSQR_MI_SUCCESS;
+}
+
 static int stream_of_calls(const CallEnv& env, int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                            size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
+	if (!env.dist && g_set.loop_depth.load() >= 3) {
+		const int st = stream_of_calls_chained(count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
+		if (st != -2) return st;
+	}
 	tsqr_mi_ticket tk[2];
 	int st = submit_impl(env, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream, &tk[0], nullptr, /*own_flag=*/count == 1);
 	if (st) return st;
@@ -1343,7 +1458,7 @@ static int stream_of_calls(const CallEnv& env, int count, int mode, int reorth, 
 	return TSQR_MI_SUCCESS;
 }
 
-void tsqr_mi_set_loop_depth(int depth) { g_set.loop_depth = depth < 2 ? 1 : 2; }
+void tsqr_mi_set_loop_depth(int depth) { g_set.loop_depth = depth < 2 ? 1 : (depth == 2 ? 2 : 3); }
 
 // `count` calls with the same arguments: the reference's speed protocol (src/test.cu:299-309 is such a C++ loop around its call).
 // Two calls in flight (submit i + 1, then finish i) unless tsqr_mi_set_loop_depth(1).  Returns the first non-zero state.
