@@ -116,15 +116,22 @@ int tsqr_mi_qr_f32_finish(tsqr_mi_ticket* ticket);
 
 /* `count` calls of tsqr_mi_qr_f32 with the same arguments -- the loop of the reference's speed protocol (reference
  * src/test.cu:299-309) on this side of the ABI, so that a host in an interpreted language times what a C++ caller's loop costs.
- * Like the reference's loop it keeps the stream fed: call i + 1 is submitted before call i is finished (submit / finish above,
- * two in flight); every call runs all of its kernels and every verdict is looked at.  tsqr_mi_set_loop_depth(1) makes it a loop of
- * plain blocking calls (the latency of one call rather than the throughput of a stream of them).  Returns the first non-zero state. */
+ * The loop knows that another call follows and keeps the stream fed (tsqr_mi_set_loop_depth selects how far it goes):
+ *   depth 1  plain blocking calls, one host round trip between two of them (the latency of a call);
+ *   depth 2  two calls in flight: call i + 1 is submitted before call i is finished (submit / finish above); inside the loop the
+ *            completion word of call i is raised by the first kernel of call i + 1 instead of a kernel of its own;
+ *   depth 3  (default) depth 2, and for full 64-column matrices of 128 k <= 2^20 rows (16-byte aligned, no reorth) the chained
+ *            schedule: the R-factor chain of call i (reduction of the Gram partials, Cholesky, verdict -- one workgroup busy, the
+ *            rest of the chip idle) runs INSIDE the launch that is the Gram pass of call i + 1, so a call costs its two streaming
+ *            passes and nothing else.  Needs count >= 3; wr holds two sets of Gram partials for it.
+ * At every depth every call runs all of its kernels, every verdict is read, a rejected matrix gets its whole ladder, and Q and R
+ * are bit for bit those of the blocking call (tests/test_gpu_async.py).  Returns the first non-zero state. */
 int tsqr_mi_qr_f32_loop(int count, int mode, int reorth,
                         float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                         size_t m, size_t n,
                         void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
                         void* stream);
-void tsqr_mi_set_loop_depth(int depth);   /* 1: blocking calls, 2 (default): two calls in flight */
+void tsqr_mi_set_loop_depth(int depth);   /* 1, 2 or 3 (default); applies to every *_loop entry of the process */
 
 /*
  * The fp16 I/O modes: replaces mtk::qr::qr<fp16_notc | fp16_tc_nocor, Reorthogonalize> (reference src/blockqr.cu:437-449; io type
@@ -203,7 +210,8 @@ int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t 
  *   (dlsym(RTLD_DEFAULT, ...)) -- the copy the caller's own ncclCommInitRank came from; TSQR_MI_ERROR_UNSUPPORTED when they are not there.
  * tsqr_mi_qr_f32_dist_cb: caller-supplied collectives (blocking or stream-ordered; in place sum / gather in rank order), e.g.
  *   torch.distributed over gloo -- what the multi-process tests use.
- * *_loop: `count` back-to-back calls (see tsqr_mi_qr_f32_loop); every rank must pass the same count. */
+ * *_loop: `count` calls as a stream (see tsqr_mi_qr_f32_loop; depths 2 and 3 both mean two calls in flight here); every rank must
+ *   pass the same count -- the ranks take the same verdicts, hence the same path through the loop and the same order of collectives. */
 size_t tsqr_mi_working_q_size_dist(size_t m_local, size_t n, int nranks);
 size_t tsqr_mi_working_r_size_dist(size_t m_local, size_t n, int nranks);
 int tsqr_mi_qr_f32_dist(int mode, int reorth,

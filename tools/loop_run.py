@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline workload in a plain loop for profilers: loop_run.py [calls] [m] [n] [mode] [reorth] [policy] [loop depth]
-(default 400 calls of 2^20 x 64 fp32_tc_cor through the C-side loop tsqr_mi_qr_f32_loop, two calls in flight; depth 1 = blocking calls)."""
+(default 400 calls of 2^20 x 64 fp32_tc_cor through the C-side loop tsqr_mi_qr_f32_loop, its default schedule; depth 1 = blocking calls, 2 = two in flight)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 mode = bq.compute_mode[sys.argv[4]] if len(sys.argv) > 4 else bq.compute_mode.fp32_tc_cor
 reorth = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
 bq.set_policy(int(sys.argv[6]) if len(sys.argv) > 6 else 0)
-bq.set_loop_depth(int(sys.argv[7]) if len(sys.argv) > 7 else 2)
+bq.set_loop_depth(int(sys.argv[7]) if len(sys.argv) > 7 else 3)
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 a = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
 keep = a.clone() if n > 64 else None

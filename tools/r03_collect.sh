@@ -14,15 +14,8 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $O/r03_kb -o b -- python
 python3 tools/kstats.py $O/r03_kb/b_kernel_stats.csv $O/r03_rocprofv3_kernel_stats_bench.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline (2^20 x 64 fp32_tc_cor: 1 checked call + first window 5+20 + 20 under HIP events + window 5+20 = 71 calls)"
 rm -rf $O/r03_kb
 
-step "per-call timelines (tools/loop_run.py, 400 calls)"
-tools/gpu_timeline.sh r03_c2 -- 400
-tools/gpu_timeline.sh r03_c2_notc -- 400 1048576 64 fp32_notc
-tools/gpu_timeline.sh r03_c3 -- 200 1048576 128 fp32_tc_cor
-tools/gpu_timeline.sh r03_c3_notc -- 200 1048576 128 fp32_notc
-tools/gpu_timeline.sh r03_reorth -- 200 1048576 64 fp32_tc_cor 1
-tools/gpu_timeline.sh r03_policy1_tc_cor -- 100 1048576 64 fp32_tc_cor 0 1
-tools/gpu_timeline.sh r03_policy1_notc -- 100 1048576 64 fp32_notc 0 1
-tools/gpu_timeline.sh r03_2p23 -- 120 8388608 64 fp32_tc_cor
+step "per-call timelines (tools/loop_run.py, 400 calls; the loop entry's default schedule unless a depth is given: 1 = blocking calls, 2 = two in flight)"
+bash tools/r03_timelines.sh
 
 step "HBM traffic of the headline kernels (two --pmc passes)"
 for cnt in FETCH_SIZE WRITE_SIZE; do

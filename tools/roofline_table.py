@@ -5,9 +5,12 @@ section 4) over its median duration, against 8 TB/s HBM and the 157.3 TF/s fp32 
 import os, re
 R = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 WORK = [  # (timeline file, label, m, n)
-    ("r03_timeline_c2.txt", "2^20 x 64 fp32_tc_cor (headline)", 1 << 20, 64),
+    ("r03_timeline_c2.txt", "2^20 x 64 fp32_tc_cor (headline; stream of calls, chained schedule)", 1 << 20, 64),
+    ("r03_timeline_c2_two_in_flight.txt", "2^20 x 64 fp32_tc_cor (stream of calls, two in flight)", 1 << 20, 64),
+    ("r03_timeline_c2_blocking.txt", "2^20 x 64 fp32_tc_cor (blocking calls)", 1 << 20, 64),
     ("r03_timeline_c2_notc.txt", "2^20 x 64 fp32_notc", 1 << 20, 64),
-    ("r03_timeline_c3.txt", "2^20 x 128 fp32_tc_cor (one panel)", 1 << 20, 128),
+    ("r03_timeline_c3.txt", "2^20 x 128 fp32_tc_cor (one panel; stream of calls, two in flight)", 1 << 20, 128),
+    ("r03_timeline_c3_blocking.txt", "2^20 x 128 fp32_tc_cor (one panel; blocking calls)", 1 << 20, 128),
     ("r03_timeline_c3_notc.txt", "2^20 x 128 fp32_notc (one panel)", 1 << 20, 128),
     ("r03_timeline_reorth.txt", "2^20 x 64 fp32_tc_cor, reorth", 1 << 20, 64),
     ("r03_timeline_policy1_tc_cor.txt", "2^20 x 64 fp32_tc_cor, Householder engine", 1 << 20, 64),

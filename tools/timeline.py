@@ -15,7 +15,7 @@ skip = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 flags_only = len(sys.argv) > 4 and sys.argv[4] == "flags"
 calls, cur = [], []
 for r in rows:
-    if cur and not flags_only and cur[-1][2].startswith("apply_") and r[2].startswith(("gram_", "fold_kernel")):
+    if cur and not flags_only and cur[-1][2].startswith("apply_") and r[2].startswith(("gram_blk", "gram_bf16", "gram_wide", "gram_kernel", "gram_h_", "fold_kernel")):
         calls.append(cur); cur = []
     cur.append(r)
     if r[2].startswith("host_flag"):
