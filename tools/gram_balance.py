@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""How evenly does the static partition of the Gram pass finish?  gram_blk_kernel's body with a start and an end stamp per workgroup
+and the XCD / CU it ran on (selftest library): end times per XCD, per position in the dispatch order, and what a balanced pass would take."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+L = ctypes.CDLL(os.path.join(ROOT, "tsqr_gpu_amd", "csrc", "libtsqr_selftest.so"))
+L.tsqr_selftest_gram_balance.restype = ctypes.c_int
+L.tsqr_selftest_gram_balance.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+g = torch.Generator(device="cuda"); g.manual_seed(5)
+a = torch.rand(64, m, generator=g, device="cuda") * 2 - 1
+nparts = min(m // 128, 512)
+part = torch.zeros(nparts * 2560, dtype=torch.float64, device="cuda")
+shares = [int(x) for x in sys.argv[2:]] or [16, 18, 19, 20, 21, 22]
+for share in shares * 2:
+    rep = share
+    st = torch.zeros(4 * nparts, dtype=torch.int64, device="cuda")
+    assert L.tsqr_selftest_gram_balance(a.data_ptr(), m, m, nparts, part.data_ptr(), st.data_ptr(), 30, share) == 0
+    t = st.cpu().numpy().reshape(nparts, 4)
+    t0 = t[:, 0].min()
+    start, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0
+    xcc = t[:, 2] & 0xF
+    hw = t[:, 3]
+    cu, sh, se = hw >> 8 & 0xF, hw >> 12 & 1, hw >> 13 & 7
+    dur = end - start
+    print("older workgroup's share %d / 32: starts %.1f .. %.1f us; ends min %.1f  median %.1f  max %.1f us; mean duration %.1f us (a balanced pass: ~%.1f us)" % (
+        rep, start.min(), start.max(), end.min(), np.median(end), end.max(), dur.mean(), dur.mean()))
+    print("  per XCD (id: workgroups, mean / max end): " + "  ".join("%d: %d, %.1f / %.1f" % (x, (xcc == x).sum(), end[xcc == x].mean(), end[xcc == x].max()) for x in sorted(set(xcc))))
+    q = nparts // 4
+    print("  by position in the grid (quarters of the workgroup index), mean end: " + "  ".join("%.1f" % end[i * q:(i + 1) * q].mean() for i in range(4)))
+    # two workgroups per CU: do CU-mates end together?
+    key = xcc * 4096 + se * 256 + sh * 16 + cu
+    pairs = [end[key == k] for k in set(key) if (key == k).sum() == 2]
+    if pairs:
+        d = np.array([abs(p[0] - p[1]) for p in pairs])
+        print("  %d CUs with two workgroups: |end difference| median %.1f us; spread of the CU means %.1f .. %.1f us" % (len(pairs), np.median(d), min(p.mean() for p in pairs), max(p.mean() for p in pairs)))

@@ -123,6 +123,31 @@ extern "C" int tsqr_selftest_chain(const float* a, size_t lda, size_t m, int npa
 	return (int)hipGetLastError();
 }
 
+// ---- gram_blk_kernel's body with a start and an end stamp per workgroup (s_memrealtime, 100 MHz) and where it ran (XCC_ID, HW_ID):
+// how evenly the static partition of the Gram pass finishes (tools/gram_balance.py) ----
+__global__ __launch_bounds__(256, 2) void gram_blk_stamp_kernel(const tsqrmi::GramArgs a, unsigned long long* stamps) {
+	extern __shared__ __attribute__((aligned(16))) float gb_as_st[];
+	unsigned long long t0 = 0;
+	if (threadIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
+	tsqrmi::gram_blk_body(a, gb_as_st, blockIdx.x, gridDim.x);
+	if (threadIdx.x == 0) {
+		unsigned xcc, hw;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+		stamps[4 * blockIdx.x + 0] = t0;
+		stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+		stamps[4 * blockIdx.x + 2] = xcc;
+		stamps[4 * blockIdx.x + 3] = hw;
+	}
+}
+extern "C" int tsqr_selftest_gram_balance(const float* a, size_t lda, size_t m, int nparts, double* part, unsigned long long* stamps, int warm, int old_share) {
+	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_blk_stamp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES);
+	tsqrmi::GramArgs ga{};
+	ga.a = a; ga.lda = lda; ga.m = m; ga.n = 64; ga.nchunks = (int)(m / 128); ga.part = part; ga.old_share = old_share;
+	for (int i = 0; i <= warm; i++) hipLaunchKernelGGL(gram_blk_stamp_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, 0, ga, stamps);
+	return (int)hipDeviceSynchronize();
+}
+
 // ---- in-kernel time stamps of chol16_kernel (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----
 extern "C" int tsqr_selftest_chol_stamps(unsigned long long* out_dev, float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT,
                                          int level, double rows) {

@@ -642,6 +642,7 @@ struct GramArgs {
 	                                     // sweep this pass depends on was rejected; its successor Cholesky reports "rejected" too)
 	unsigned* announce; unsigned announce_seq;   // optional: completion word (pinned host memory) of the CALL IN FRONT of this one in the
 	                                     // stream and the value to raise it to
+	int old_share;                       // 0 (= GB_OLD_SHARE); tools/gram_balance.py: share of a CU's blocks (in 32nds) for its first workgroup
 };
 
 // A stream of calls (tsqr_mi_qr_f32_loop): the first kernel of call i + 1 starts when the last kernel of call i has finished (stream
@@ -944,6 +945,7 @@ __global__ __launch_bounds__(256) void gram_h_kernel(const GramArgs a) {
 // totals -- tools/gram_accuracy.py, profiles/r03_experiment_log.md.)
 // Partials in the same format as gram_bf16_kernel.
 constexpr int GB_ROWS = 128, GB_RS = 136;
+constexpr int GB_OLD_SHARE = 20;                       // of 32: the share of a CU's blocks its first (older) workgroup takes (gram_blk_body)
 constexpr int GB_LDS_BYTES = 2 * 64 * GB_RS * 4;
 // (the body takes its workgroup number and the number of Gram workgroups as arguments: gram_blk_chain_kernel below runs it on a part of
 // its grid)
@@ -955,7 +957,24 @@ __device__ __forceinline__ void gram_blk_body(const GramArgs& a, float* gb_as, c
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int c = lane & 15, q = lane >> 4;
 	const int lcol = lane >> 5, lrow = 4 * (lane & 31);
-	const int nblk = a.nchunks, step = nwg;              // 128-row blocks (the host sends only m % 128 == 0, n == 64, 16-byte aligned columns, lda < 2^23)
+	const int nblk = a.nchunks;                          // 128-row blocks (the host sends only m % 128 == 0, n == 64, 16-byte aligned columns, lda < 2^23)
+	// Which blocks are this workgroup's.  The grid is twice the CUs and the dispatcher fills every CU once, then again: workgroups w and
+	// w + nwg / 2 share a CU, and the instruction arbiter prefers the older one -- with equal shares the first workgroup of a CU was
+	// done at 35 us, the second at 44.5, its last 9 us alone on a CU that needs two workgroups to hide its latencies (stamps:
+	// tools/gram_balance.py).  So the blocks of a pair p, p + half, p + 2 half, ... are split unevenly: the first GB_OLD_SHARE / 32 of
+	// them to the older workgroup, the rest to the younger.  A fixed function of (w, nwg, blocks): the partials are the same
+	// whichever launch runs this body.
+	int first = wg, step = nwg, bend = nblk;
+	if ((nwg & 1) == 0 && nblk >= 2 * nwg) {
+		const int half = nwg >> 1, p = wg < half ? wg : wg - half;
+		const int K = (nblk - p + half - 1) / half;
+		const int H = (K * (a.old_share ? a.old_share : GB_OLD_SHARE) + 16) >> 5;
+		step = half;
+		first = wg < half ? p : p + half * H;
+		bend = wg < half ? p + half * H : p + half * K;
+	}
+	// this workgroup's last block: where a look-ahead load past its end goes (a workgroup without blocks loads some valid block and uses nothing)
+	const int blast = first < bend ? first + ((bend - 1 - first) / step) * step : min(first, nblk - 1);
 	f64x4 tot[NTRI];
 #pragma unroll
 	for (int t = 0; t < NTRI; t++) tot[t] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -966,7 +985,7 @@ __device__ __forceinline__ void gram_blk_body(const GramArgs& a, float* gb_as, c
 	const unsigned soff0 = (unsigned)((size_t)(2 * wv) * a.lda * sizeof(float)), soffk = (unsigned)(8 * a.lda * sizeof(float));
 	auto load_block = [&](f32x4 (&v)[8], int b) {
 		// (no branch at all: past the end the last block is simply loaded again and never used)
-		const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a + (size_t)min(b, nblk - 1) * GB_ROWS), 0, -1, 0x00020000);
+		const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a + (size_t)min(b, blast) * GB_ROWS), 0, -1, 0x00020000);
 #pragma unroll
 		for (int k = 0; k < 8; k++) v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff0 + k * soffk, 0));
 	};
@@ -1018,26 +1037,26 @@ __device__ __forceinline__ void gram_blk_body(const GramArgs& a, float* gb_as, c
 	// register sets X, Y and two block buffers; the loop head sits between "stage the next block" and "barrier" (gram_wide_kernel)
 	constexpr int BUF = 64 * GB_RS;
 	f32x4 vx[8], vy[8];
-	int bi = wg, it = 0;
+	int bi = first, it = 0;
 	load_block(vx, bi);
 	asm volatile("" ::: "memory");
 	load_block(vy, bi + step);
 	asm volatile("" ::: "memory");
-	if (bi < nblk) stage(vx, gb_as);
-	while (bi < nblk) {
+	if (bi < bend) stage(vx, gb_as);
+	while (bi < bend) {
 		lds_barrier();                                   // block `bi` is staged; every wave is done with the other buffer
 		load_block(vx, bi + 2 * step);
 		asm volatile("" ::: "memory");
 		products(gb_as + (it & 1) * BUF);
 		bi += step; it++;
-		if (bi >= nblk) break;
+		if (bi >= bend) break;
 		stage(vy, gb_as + (it & 1) * BUF);
 		lds_barrier();
 		load_block(vy, bi + 2 * step);
 		asm volatile("" ::: "memory");
 		products(gb_as + (it & 1) * BUF);
 		bi += step; it++;
-		if (bi >= nblk) break;
+		if (bi >= bend) break;
 		stage(vx, gb_as + (it & 1) * BUF);
 	}
 	// workgroup sum in fp64: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the partial
