@@ -9,6 +9,26 @@ import torch
 L = ctypes.CDLL(os.path.join(ROOT, "tsqr_gpu_amd", "csrc", "libtsqr_selftest.so"))
 L.tsqr_selftest_gram_balance.restype = ctypes.c_int
 L.tsqr_selftest_gram_balance.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+if len(sys.argv) > 1 and sys.argv[1] == "apply":
+    # the apply pass: 1024 workgroups (four per CU), each 16 blocks of 64 rows
+    L.tsqr_selftest_apply_balance.restype = ctypes.c_int
+    L.tsqr_selftest_apply_balance.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    m = 1 << 20
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    a = torch.rand(64, m, generator=g, device="cuda") * 2 - 1
+    q = torch.empty(64, m, device="cuda")
+    z = torch.triu(torch.rand(64, 64, generator=g, device="cuda")).T.contiguous()
+    for nwg in (1024, 1024, 768, 512):
+        st = torch.zeros(4 * nwg, dtype=torch.int64, device="cuda")
+        assert L.tsqr_selftest_apply_balance(q.data_ptr(), a.data_ptr(), m, m, z.data_ptr(), nwg, st.data_ptr(), 30) == 0
+        t = st.cpu().numpy().reshape(nwg, 4)
+        t0 = t[:, 0].min()
+        start, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0
+        print("apply pass, %d workgroups: starts %.1f .. %.1f us; ends min %.1f  median %.1f  max %.1f us; mean duration %.1f us" % (
+            nwg, start.min(), start.max(), end.min(), np.median(end), end.max(), (end - start).mean()))
+        q4 = nwg // 4
+        print("  by position in the grid (quarters of the workgroup index), mean end: " + "  ".join("%.1f" % end[i * q4:(i + 1) * q4].mean() for i in range(4)))
+    sys.exit(0)
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 g = torch.Generator(device="cuda"); g.manual_seed(5)
 a = torch.rand(64, m, generator=g, device="cuda") * 2 - 1

@@ -11,7 +11,7 @@ step() { echo "== $*"; }
 step "kernel stats of: python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
 rm -rf $O/r03_kb
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/r03_kb -o b -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/r03_bench_under_rocprof.json 2> $O/r03_kb.err || { tail -5 $O/r03_kb.err; exit 1; }
-python3 tools/kstats.py $O/r03_kb/b_kernel_stats.csv $O/r03_rocprofv3_kernel_stats_bench.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline (2^20 x 64 fp32_tc_cor: 1 checked call + first window 5+20 + 20 under HIP events + window 5+20 = 71 calls)"
+python3 tools/kstats.py $O/r03_kb/b_kernel_stats.csv $O/r03_rocprofv3_kernel_stats_bench.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline (2^20 x 64 fp32_tc_cor: 1 checked call + first window 5+20 + 20 under HIP events + window 5+20 + blocking-calls window 5+20 = 96 calls)"
 rm -rf $O/r03_kb
 
 step "per-call timelines (tools/loop_run.py, 400 calls; the loop entry's default schedule unless a depth is given: 1 = blocking calls, 2 = two in flight)"

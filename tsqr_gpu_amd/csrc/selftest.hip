@@ -148,6 +148,32 @@ extern "C" int tsqr_selftest_gram_balance(const float* a, size_t lda, size_t m, 
 	return (int)hipDeviceSynchronize();
 }
 
+// ---- the apply pass (apply_wg_kernel<1, 4, false, 64>: Q = A * Z, bf16x3) with a start and an end stamp per workgroup: how evenly the
+// four workgroups of a CU finish (tools/gram_balance.py apply) ----
+__global__ __launch_bounds__(256) void apply_stamp_kernel(const tsqrmi::ApplyArgs a, unsigned long long* stamps) {
+	unsigned long long t0 = 0;
+	if (threadIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
+	tsqrmi::apply_wg_body<1, 4, false, 64, false>(a);
+	if (threadIdx.x == 0) {
+		unsigned xcc, hw;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+		stamps[4 * blockIdx.x + 0] = t0;
+		stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+		stamps[4 * blockIdx.x + 2] = xcc;
+		stamps[4 * blockIdx.x + 3] = hw;
+	}
+}
+extern "C" int tsqr_selftest_apply_balance(float* q, const float* a, size_t ld, size_t m, const float* z, int nwg, unsigned long long* stamps, int warm) {
+	constexpr size_t lds = sizeof(float) * 64 * (64 + 4) + (size_t)3 * 6 * 512 * 2;
+	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_stamp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	tsqrmi::ApplyArgs aa{};
+	aa.a = a; aa.lda = ld; aa.q = q; aa.ldq = ld; aa.m = m; aa.n = 64; aa.z = z;
+	aa.nchunks = (int)((m + 63) / 64); aa.nwaves = nwg; aa.cpw = 0;
+	for (int i = 0; i <= warm; i++) hipLaunchKernelGGL(apply_stamp_kernel, dim3(nwg), dim3(256), lds, 0, aa, stamps);
+	return (int)hipDeviceSynchronize();
+}
+
 // ---- in-kernel time stamps of chol16_kernel (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----
 extern "C" int tsqr_selftest_chol_stamps(unsigned long long* out_dev, float* r, size_t ldr, float* z, unsigned* status, const double* gsum, int n, int NT,
                                          int level, double rows) {
