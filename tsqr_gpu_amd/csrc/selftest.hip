@@ -164,12 +164,14 @@ __global__ __launch_bounds__(256) void apply_stamp_kernel(const tsqrmi::ApplyArg
 		stamps[4 * blockIdx.x + 3] = hw;
 	}
 }
-extern "C" int tsqr_selftest_apply_balance(float* q, const float* a, size_t ld, size_t m, const float* z, int nwg, unsigned long long* stamps, int warm) {
+extern "C" int tsqr_selftest_apply_balance(float* q, const float* a, size_t ld, size_t m, const float* z, int nwg, unsigned long long* stamps, int warm,
+                                           int s0, int s1, int s2, int s3, int even_share) {
 	constexpr size_t lds = sizeof(float) * 64 * (64 + 4) + (size_t)3 * 6 * 512 * 2;
 	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_stamp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	tsqrmi::ApplyArgs aa{};
 	aa.a = a; aa.lda = ld; aa.q = q; aa.ldq = ld; aa.m = m; aa.n = 64; aa.z = z;
 	aa.nchunks = (int)((m + 63) / 64); aa.nwaves = nwg; aa.cpw = 0;
+	aa.share[0] = s0; aa.share[1] = s1; aa.share[2] = s2; aa.share[3] = s3; aa.even_share = even_share;
 	for (int i = 0; i <= warm; i++) hipLaunchKernelGGL(apply_stamp_kernel, dim3(nwg), dim3(256), lds, 0, aa, stamps);
 	return (int)hipDeviceSynchronize();
 }

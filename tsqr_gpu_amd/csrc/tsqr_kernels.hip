@@ -1860,6 +1860,9 @@ struct ApplyArgs {
 	const unsigned* skip_status;        // optional: the kernel returns at once when *skip_status != 0 (the Cholesky kernel
 	                                    // rejected its Gram matrix: a speculatively enqueued apply then costs a launch, not a pass)
 	const float* r32; void* r16; size_t ldr16;   // fp16 I/O only, optional: workgroup 0 also rounds the n x n factor r32 (ld n) to the caller's half-typed R
+	int share[4];                       // all zero: blocks interleaved over the grid.  Otherwise (grid = four workgroups per CU, dispatched in four
+	                                    // rounds): 64ths of a CU's blocks for its first .. fourth workgroup (apply_wg_body) and
+	int even_share;                     // 128ths of the blocks of two neighbouring CUs (even XCD, odd XCD) for the one on the even XCD
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1914,7 +1917,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	const int lcol = lane / LPC, lrow = 4 * (lane % LPC);
 
 	const int nblk = a.nchunks, nwg = a.nwaves;
-	auto blk = [&](int i) { return nblk - 1 - i; };      // (block order does not matter to the Infinity Cache: tools/seq_bench.py)
+	// (block order does not matter to the Infinity Cache: tools/seq_bench.py; blk() below)
 	auto swz = [](int col) { return ((col >> 3) & 1) << 4; };
 	auto load_block = [&](f32x4 (&v)[NI], const auto* base, size_t ld, int ncols, int b) {
 		using T = std::remove_cv_t<std::remove_pointer_t<decltype(base)>>;
@@ -1952,9 +1955,42 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	// prefetch: the next block in registers (v); 64-row blocks are small enough to keep the block after it in flight as well (v2)
 	constexpr bool DEEP = (ROWS == 64 && !UPD) || NW == 8 || sizeof(IO) == 2;      // (half I/O: a block is half the bytes -- keep two in flight)
 	f32x4 v[NI], v2[DEEP ? NI : 1];
-	int bi = blockIdx.x;
-	if (bi < nblk) load_block(v, a_in, a.lda, a.n, blk(bi));
-	if constexpr (DEEP) { if (bi + nwg < nblk) load_block(v2, a_in, a.lda, a.n, blk(bi + nwg)); }
+	// Which blocks are this workgroup's: ordinals w, w + nwg, ... by default.  With a.share set (grid = four workgroups per CU,
+	// blocks a multiple of the CUs) the shares are uneven, because the workgroups are (stamps of every workgroup, tools/gram_balance.py
+	// apply; 2^20 x 64, equal shares: the pass ends at 84 us, the mean workgroup at 66):
+	//   * not equally fast by XCD: workgroup w runs on XCD w mod 8, and the odd XCDs move their blocks 15 % slower than the even ones
+	//     (mean end 72 against 62 us on every box looked at) -- the even XCDs then idle for the last 10 us of the pass;
+	//   * not equals on a CU: the dispatcher places w, w + nwg/4, w + nwg/2, w + 3 nwg/4 on one CU in four rounds and the CU prefers
+	//     the older ones (57 / 63 / 70 / 75 us).
+	// Two neighbouring CU groups p = 2 pp (even XCD) and p + 1 (odd XCD) pool their blocks -- ordinals 2 pp + (j & 1) + (nwg/4)(j >> 1),
+	// j = 0 .. 2K-1 -- the even group takes the first a.even_share / 128 of that list, and inside a group the four workgroups take
+	// contiguous runs of a.share[rank] / 64.  (Every block is computed on its own: Q does not depend on who computes it.)
+	const int quarter = nwg >> 2;
+	const bool uneven = a.share[0] != 0 && (nwg & 7) == 0 && nblk % quarter == 0 && nblk >= 16 * quarter;
+	int bi = blockIdx.x, bstep = nwg, bend = nblk, pair_base = 0;
+	if (uneven) {
+		const int p = (int)blockIdx.x % quarter, rank = (int)blockIdx.x / quarter;
+		const int K2 = 2 * (nblk / quarter);
+		const int E = (K2 * a.even_share + 64) >> 7;
+		const int g0 = (p & 1) ? E : 0, len = (p & 1) ? K2 - E : E;
+		int lo = 0, hi = 0, acc = 0;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int nxt = acc + a.share[r];
+			if (r == rank) { lo = (len * acc + 32) >> 6; hi = (r == 3) ? len : (len * nxt + 32) >> 6; }
+			acc = nxt;
+		}
+		pair_base = p & ~1;
+		bstep = 1;
+		bi = g0 + lo;
+		bend = g0 + hi;
+	}
+	auto blk = [&](int i) {                              // i: position in this workgroup's progression -> block (reverse order: as good as any)
+		const int ordinal = uneven ? pair_base + (i & 1) + quarter * (i >> 1) : i;
+		return nblk - 1 - ordinal;
+	};
+	if (bi < bend) load_block(v, a_in, a.lda, a.n, blk(bi));
+	if constexpr (DEEP) { if (bi + bstep < bend) load_block(v2, a_in, a.lda, a.n, blk(bi + bstep)); }
 	// (the verdict word is looked at only now: its round trip runs under the loads just issued; a skipped launch has merely
 	// requested a block or two of an input that is valid either way)
 	if (a.skip_status && a.skip_status[0] != 0) return;  // uniform over the grid
@@ -2029,7 +2065,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 		}
 	}
 
-	for (; bi < nblk; bi += nwg) {
+	for (; bi < bend; bi += bstep) {
 		const int b = blk(bi);
 #pragma unroll
 		for (int k = 0; k < NI; k++) {
@@ -2040,9 +2076,9 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 		if constexpr (DEEP) {
 #pragma unroll
 			for (int k = 0; k < NI; k++) v[k] = v2[k];
-			if (bi + 2 * nwg < nblk) load_block(v2, a_in, a.lda, a.n, blk(bi + 2 * nwg));
+			if (bi + 2 * bstep < bend) load_block(v2, a_in, a.lda, a.n, blk(bi + 2 * bstep));
 		} else {
-			if (bi + nwg < nblk) load_block(v, a_in, a.lda, a.n, blk(bi + nwg));
+			if (bi + bstep < bend) load_block(v, a_in, a.lda, a.n, blk(bi + bstep));
 		}
 		f32x4 cin[UPD ? NI : 1];
 		if constexpr (UPD) load_block(cin, a.q, a.ldq, a.n_out, b);

@@ -609,6 +609,11 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 		a.gpart = c.gramq_part;
 		c.gramq_nparts = a.nwaves;
 	}
+	if constexpr (!UPD && !GRAMQ && ROWS == 64) {
+		// four workgroups per CU on the whole chip: uneven shares by XCD parity and by dispatch round (apply_wg_body; measured on
+		// 2^20 x 64: the pass ends at 78 us instead of 84)
+		if (a.nwaves == 1024 && per_cu_cache[c.dev].load() == 4) { a.share[0] = 18; a.share[1] = 17; a.share[2] = 15; a.share[3] = 14; a.even_share = 69; }
+	}
 	hipLaunchKernelGGL(kernel, dim3(a.nwaves), dim3(256), lds, c.st, a);
 	return 0;
 }
