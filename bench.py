@@ -399,9 +399,11 @@ def main():
             out["rehearsal"] = True
             out["data"] = "synthetic (CPU rehearsal with the numpy test double: NOT a measurement of the product)"
         if blocking_ms is not None:
-            out["call_protocol"] = ("stream of calls from one C loop, two in flight (call i + 1 submitted before call i is finished); every call runs "
-                                    "all of its kernels and its conditioning verdict is read; `blocking_calls` is the same window with one "
-                                    "blocking call after the other")
+            out["call_protocol"] = ("the K calls of the window are ONE call of the C loop entry (tsqr_mi_qr_f32_loop / _dist_*_loop), issued as a stream: call i + 1 "
+                                    "is submitted before call i is finished (two in flight); for full 64-column matrices of <= 2^20 rows on one GPU the "
+                                    "R-factor chain of call i (reduction, Cholesky, verdict) runs inside the Gram launch of call i + 1.  Every call runs "
+                                    "all of its kernels, every conditioning verdict is read, Q and R are bit for bit those of the blocking call; "
+                                    "`blocking_calls` is the same window with one blocking call after the other (tsqr_mi_set_loop_depth(1))")
             out["blocking_calls"] = {"ms_per_step": blocking_ms, "value": flops / (blocking_ms * 1e-3) / 1e9, "unit": "GFLOP/s"}
         if first_ms is not None:
             out["first_window"] = {"ms_per_step": first_ms, "value": flops / (first_ms * 1e-3) / 1e9, "unit": "GFLOP/s",
