@@ -229,3 +229,30 @@ def test_row_partitioned_driver_exactly_dependent_columns(env):
     torch.cuda.synchronize()
     assert eng.last_engine == 4
     assert harness.residual(d_q, d_r, d_a, m, n) < 2e-6 and harness.orthogonality_fro(d_q, m, n) < 1.01
+
+
+@pytest.mark.parametrize("m", [1 << 18, 1 << 19, 3 << 18, 65 << 14, (1 << 20) - 16384, (1 << 20) + 64])
+@pytest.mark.parametrize("mode", ["fp32_tc_cor", "fp32_notc"])
+def test_64_columns_block_shares_of_the_two_passes(env, m, mode):
+    """Row counts around the conditions of the uneven block shares (Gram pass: a CU's blocks 20 : 12 between its two workgroups; apply
+    pass: 69 : 59 between the CUs of an even and an odd XCD, 18 / 17 / 15 / 14 inside a CU -- only for grids that fill the chip and
+    block counts that divide evenly): every block is computed exactly once whatever the split -- residual and orthogonality at
+    rounding level, Q finite everywhere, nothing written beyond row m."""
+    torch, bq, harness, oracle = env
+    n = 64
+    g = torch.Generator(device="cuda"); g.manual_seed(m & 0xFFFF)
+    ld = m + 64
+    d_a = torch.zeros(n, ld, device="cuda")
+    d_a[:, :m] = torch.rand(n, m, generator=g, device="cuda") * 2 - 1
+    d_q = torch.full((n, ld), float("nan"), device="cuda")
+    d_r = torch.zeros(n, n, device="cuda")
+    md = bq.compute_mode[mode]
+    bf = bq.buffer(md, False); bf.allocate(m, n)
+    assert bq.qr(d_q, ld, d_r, n, d_a, ld, m, n, bf) == 0 and bq.last_engine() == 3
+    assert torch.isnan(d_q[:, m:]).all() and torch.isfinite(d_q[:, :m]).all()
+    q = d_q[:, :m].contiguous(); a = d_a[:, :m].contiguous()
+    assert harness.orthogonality_fro(q, m, n) < 5e-6 and harness.residual(q, d_r, a, m, n) < 5e-7
+    # and the loop entry (stream of calls) returns the same bits
+    d_q2 = torch.full((n, ld), float("nan"), device="cuda"); d_r2 = torch.zeros(n, n, device="cuda")
+    assert bq.bind_loop(d_q2, ld, d_r2, n, d_a, ld, m, n, bf)(4) == 0
+    assert torch.equal(d_q2[:, :m], d_q[:, :m]) and torch.equal(d_r2, d_r)
