@@ -340,7 +340,7 @@ def main():
     ms_per_step = timed_window()
     # 5. the same window with the loop entry degraded to plain blocking calls (one host round trip per call): reported, not `value`
     blocking_ms = None
-    if gpu and not args.rehearse and not io_half:             # (every rank alike: the loop depth is a per-process setting)
+    if gpu and not args.rehearse:                             # (every rank alike: the loop depth is a per-process setting)
         bq.set_loop_depth(1)
         try:
             blocking_ms = timed_window()

@@ -183,3 +183,28 @@ def test_cpp_sample_runs_the_fp16_modes(bq, torch_cuda):
     out = subprocess.check_output([os.path.join(root, "tests", "cpp", "sample_blockqr")], text=True)
     lines = [l for l in out.splitlines() if l.startswith("mode=")]
     assert "SAMPLE OK" in out and {l.split()[0] for l in lines} >= {"mode=0", "mode=1", "mode=2", "mode=3"}, out
+
+
+@pytest.mark.parametrize("mode", ["fp16_tc_nocor", "fp16_notc"])
+@pytest.mark.parametrize("m,n,kind", [(1 << 17, 64, "uniform"), (20000, 48, "uniform"), (30000, 64, "cond1e5"), (4096, 12, "uniform")])
+def test_loop_entry_streams_the_native_path(bq, oracle, torch_cuda, m, n, kind, mode):
+    """tsqr_mi_qr_f16_loop: calls of the native path go out as a stream, two in flight (completion word of call i raised by the Gram
+    kernel of call i + 1); a rejected matrix (cond 1e5) and n <= 16 fall back to blocking calls -- the same halves as five blocking calls."""
+    torch = torch_cuda
+    md = bq.compute_mode[mode]
+    a = oracle.uniform_matrix(m, n, seed=3) if kind == "uniform" else oracle.matrix_with_cond(m, n, 1e5, seed=3).astype(np.float32)
+    d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda().half()
+    res = []
+    for depth in (1, 3):
+        d_q = torch.full((n, m), float("nan"), dtype=torch.float16, device="cuda")
+        d_r = torch.zeros(n, n, dtype=torch.float16, device="cuda")
+        bf = bq.buffer(md, False); bf.allocate(m, n)
+        bq.set_loop_depth(depth)
+        try:
+            assert bq.bind_loop(d_q, m, d_r, n, d_a, m, m, n, bf)(5) == 0
+            eng = bq.last_engine()
+        finally:
+            bq.set_loop_depth(3)
+        res.append((d_q.cpu().numpy().copy(), d_r.cpu().numpy().copy(), eng))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    assert np.isfinite(res[1][0].astype(np.float32)).all()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the whole GPU test suite, then the bench lines of every workload (c2 headline, c3 both modes, c5) and the one-rank
+# GPU box: the whole GPU test suite, then the bench lines of every workload (c2 headline, c3 both modes, c5, Householder engine, fp16 I/O) and the one-rank
 # row-partitioned driver over raw RCCL.  Everything lands under gpurun_out/verify_*.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
@@ -23,6 +23,7 @@ run c3 --workload c3 --steps 20 --warmup 5 --no-cpu-baseline
 run c3notc --workload c3 --mode fp32_notc --steps 20 --warmup 5 --no-cpu-baseline
 run c5 --workload c5 --steps 20 --warmup 5 --no-cpu-baseline
 run hh --policy 1 --steps 20 --warmup 5 --no-cpu-baseline
+run c2h --workload c2h --steps 20 --warmup 5
 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --dist-comm rccl --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/verify_bench_dist1.json 2> gpurun_out/verify_bench_dist1.err || { echo "dist1 failed"; tail -8 gpurun_out/verify_bench_dist1.err; exit 1; }
 python - <<'PY'
 import json

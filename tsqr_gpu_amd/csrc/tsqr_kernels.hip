@@ -838,6 +838,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void gram_h_kernel(const GramArgs a) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
 	__shared__ double red[2][NTRI * 256];
+	announce_previous_call(a.announce, a.announce_seq);
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
@@ -1966,7 +1967,9 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	// j = 0 .. 2K-1 -- the even group takes the first a.even_share / 128 of that list, and inside a group the four workgroups take
 	// contiguous runs of a.share[rank] / 64.  (Every block is computed on its own: Q does not depend on who computes it.)
 	const int quarter = nwg >> 2;
-	const bool uneven = a.share[0] != 0 && (nwg & 7) == 0 && nblk % quarter == 0 && nblk >= 16 * quarter;
+	// (compiled into the plain 64-row fp32 kernels only: elsewhere the extra index arithmetic cost the fp16-product kernels a workgroup per CU)
+	constexpr bool CAN_SHARE = !UPD && !GRAMQ && ROWS == 64 && NW == 4 && sizeof(IO) == 4;
+	const bool uneven = CAN_SHARE && a.share[0] != 0 && (nwg & 7) == 0 && nblk % quarter == 0 && nblk >= 16 * quarter;
 	int bi = blockIdx.x, bstep = nwg, bend = nblk, pair_base = 0;
 	if (uneven) {
 		const int p = (int)blockIdx.x % quarter, rank = (int)blockIdx.x / quarter;

@@ -499,7 +499,7 @@ int gram_g(Ctx& c, const float* src, size_t ld, size_t m, size_t n, bool bf16, b
 	a.a = src; a.lda = ld; a.m = m; a.n = (int)n; a.nchunks = g.nch; a.cpw = g.cpw; a.nwaves = g.nwaves;
 	a.part = reinterpret_cast<double*>(c.wr);
 	a.skip_status = c.prev_slot >= 0 ? c.status_dev(c.prev_slot) : nullptr;
-	if (!io_half && !(bf16 && c.gramq_ready)) { a.announce = c.announce_word; a.announce_seq = c.announce_seq; c.announce_word = nullptr; }
+	if (!(bf16 && c.gramq_ready)) { a.announce = c.announce_word; a.announce_seq = c.announce_seq; c.announce_word = nullptr; }
 	int nparts = g.nblocks;                              // workgroups that wrote a partial
 	if (bf16 && c.gramq_ready) {                         // the previous sweep's apply kernel accumulated this very Gram matrix
 		c.gramq_ready = false;
@@ -1554,8 +1554,74 @@ int tsqr_mi_qr_f16(int mode, int reorth, void* q, size_t ldq, void* r, size_t ld
 	return tsqr_mi_stream_wait(stream);
 }
 
+// The fp16 calls as a stream, two in flight (the native path only: one panel, no reorth, aligned halves): Gram pass on the halves, reduction,
+// Cholesky + verdict, apply pass (which also rounds R), the completion word of call i raised by the Gram kernel of call i + 1.  The
+// verdict words alternate between the two halves of the pinned words.  Returns -2 when the call is not one for the native path
+// (nothing enqueued); a rejected verdict drains the stream and finishes the count with blocking calls (conversion path, whole ladder).
+static int stream_of_calls_f16(int count, int mode, void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
+                               size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
+	auto aligned16 = [](const void* p, size_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
+	const int emode = f16_engine_mode(mode);
+	if (emode < 0 || n > m || m == 0 || n == 0 || n > PW || n <= 16 || ldq < m || lda < m || ldr < n || !aligned16(a, lda) || !aligned16(q, ldq)) return -2;
+	Ctx c;
+	init_ctx(c, wq_v, wr_v, m, n, stream);
+	c.rows_global = (double)m;
+	resolve_host_sig(c, h_wl, m);
+	if (!(c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug)) return -2;
+	float* r32 = reinterpret_cast<float*>(wq_v) + f16_tail_offset(m, n) + 2 * f16_ld(m) * n;
+	const int engine = engine_of(emode);
+	volatile unsigned* words = reinterpret_cast<volatile unsigned*>(c.hsig.host);
+	unsigned seq[2] = {0, 0};
+	auto step = [&](int i) -> int {                      // every launch of call i; c.announce_word (call i - 1's completion word) rides in its Gram kernel
+		c.slot = i & 1; c.prev_slot = -1;
+		int rc = gram_g(c, reinterpret_cast<const float*>(a), lda, m, n, /*bf16=*/true, /*io_half=*/true);
+		if (!rc) rc = chol_from_g(c, r32, n, n, 2);
+		if (!rc) rc = apply_rinv(c, engine, reinterpret_cast<float*>(q), ldq, reinterpret_cast<const float*>(a), lda, r32, n, m, n, /*z_ready=*/true,
+		                         c.status_dev(c.slot), /*io_half=*/true, r, ldr);
+		if (rc) return rc;
+		unsigned sq = ++g_seq;
+		if (sq == 0) sq = ++g_seq;
+		seq[i & 1] = sq;
+		words[4 * (i & 1) + 3] = 0;
+		if (i + 1 < count) { c.announce_word = c.hsig.dev + 4 * (i & 1) + 3; c.announce_seq = sq; }
+		else hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, c.hsig.dev + 4 * (i & 1) + 3, sq);
+		HIPCHK(hipGetLastError());
+		return 0;
+	};
+	int rc = step(0);
+	if (rc) return rc;
+	for (int i = 0; i < count; i++) {
+		if (i + 1 < count) { rc = step(i + 1); if (rc) return rc; }
+		for (bool done = false; !done;) {
+			for (int k = 0; k < 20000 && !done; k++) {
+				done = (words[4 * (i & 1) + 3] == seq[i & 1]);
+				if (!done) __builtin_ia32_pause();
+			}
+			if (!done) {
+				const hipError_t e = hipStreamQuery(c.st);
+				if (e == hipSuccess) done = true;
+				else if (e != hipErrorNotReady) HIPCHK(e);
+			}
+		}
+		if (words[4 * (i & 1)] != 0) {                   // rejected: drain, then this call and the rest as blocking calls
+			HIPCHK(hipStreamSynchronize(c.st));
+			for (int k = i; k < count; k++) {
+				const int st = tsqr_mi_qr_f16(mode, 0, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, nullptr, nullptr, h_wl, stream);
+				if (st) return st;
+			}
+			return TSQR_MI_SUCCESS;
+		}
+	}
+	t_last_engine = 3;
+	return TSQR_MI_SUCCESS;
+}
+
 int tsqr_mi_qr_f16_loop(int count, int mode, int reorth, void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
                         size_t m, size_t n, void* wq_v, void* wr_v, void* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
+	if (count >= 2 && g_set.loop_depth.load() >= 2 && !reorth) {
+		const int st = stream_of_calls_f16(count, mode, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
+		if (st != -2) return st;
+	}
 	for (int i = 0; i < count; i++) {
 		const int st = tsqr_mi_qr_f16(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
 		if (st) return st;
