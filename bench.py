@@ -336,9 +336,7 @@ def main():
         prof = bq.profile_read()
         bq.profile_enable(False)
 
-    # 4. the contract's window
-    ms_per_step = timed_window()
-    # 5. the same window with the loop entry degraded to plain blocking calls (one host round trip per call): reported, not `value`
+    # 4. the same window as 5. with the loop entry degraded to plain blocking calls (one host round trip per call): reported, not `value`
     blocking_ms = None
     if gpu and not args.rehearse:                             # (every rank alike: the loop depth is a per-process setting)
         bq.set_loop_depth(1)
@@ -346,6 +344,8 @@ def main():
             blocking_ms = timed_window()
         finally:
             bq.set_loop_depth(3)
+    # 5. the contract's window
+    ms_per_step = timed_window()
     flops = f_qr(m_glob, n)
     gflops = flops / (ms_per_step * 1e-3) / 1e9
 
@@ -393,7 +393,7 @@ def main():
                    "parallelism": "row-partitioned x%d" % world,
                    "dist_transport": (eng.transport if eng is not None else None)},
                "orth_fro": orth_fro, "orth_ref_metric": orth_fro / np.sqrt(n), "residual": residual,
-               "window_order": "1 checked step, first_window (W + K), K steps under HIP events, the W + K window `value` is taken from, then blocking_calls (W + K)",
+               "window_order": "1 checked step, first_window (W + K), K steps under HIP events, blocking_calls (W + K), then the W + K window `value` is taken from",
                "roofline": roofline}
         if args.rehearse:
             out["rehearsal"] = True
