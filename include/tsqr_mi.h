@@ -211,8 +211,10 @@ int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t 
  *   (dlsym(RTLD_DEFAULT, ...)) -- the copy the caller's own ncclCommInitRank came from; TSQR_MI_ERROR_UNSUPPORTED when they are not there.
  * tsqr_mi_qr_f32_dist_cb: caller-supplied collectives (blocking or stream-ordered; in place sum / gather in rank order), e.g.
  *   torch.distributed over gloo -- what the multi-process tests use.
- * *_loop: `count` calls as a stream (see tsqr_mi_qr_f32_loop; depths 2 and 3 both mean two calls in flight here); every rank must
- *   pass the same count -- the ranks take the same verdicts, hence the same path through the loop and the same order of collectives. */
+ * *_loop: `count` calls as a stream (see tsqr_mi_qr_f32_loop); every rank must pass the same count and run at the same loop depth -- the
+ *   ranks take the same verdicts, hence the same path through the loop and the same order of collectives.  Depth 3, count >= 3: when
+ *   EVERY rank holds a full 64-column block of 128 k <= 2^20 rows (agreed on by one all-reduce of flags per loop call) the Cholesky
+ *   launch of call i rides in the Gram launch of call i + 1 and allreduce(i + 1) is enqueued before apply(i). */
 size_t tsqr_mi_working_q_size_dist(size_t m_local, size_t n, int nranks);
 size_t tsqr_mi_working_r_size_dist(size_t m_local, size_t n, int nranks);
 int tsqr_mi_qr_f32_dist(int mode, int reorth,

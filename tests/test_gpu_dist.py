@@ -190,7 +190,11 @@ def test_two_ranks_ill_conditioned_escalates_identically(oracle):
     assert np.linalg.norm(q.T @ q - np.eye(64)) < 1e-5
 
 
-@pytest.mark.parametrize("heights,cond,loop", [((30000, 17777), 1.0, 3), ((30000, 1, 7777, 12345), 1.0, 4), ((40000, 25000), 1e9, 3)])
+@pytest.mark.parametrize("heights,cond,loop", [((30000, 17777), 1.0, 3), ((30000, 1, 7777, 12345), 1.0, 4), ((40000, 25000), 1e9, 3),
+                                               # blocks of 128 k rows on every rank: the chained schedule (Cholesky of call i inside the Gram launch of call i + 1)
+                                               ((32768, 16384), 1.0, 4), ((16384, 8192, 32768, 128), 1.0, 3), ((32768, 32768), 1e9, 3),
+                                               # one rank eligible, one not: the ranks agree on the plain stream
+                                               ((32768, 17777), 1.0, 3)])
 def test_stream_of_row_partitioned_calls(oracle, heights, cond, loop):
     """The C loop entry with two calls in flight on every rank: call i + 1 (Gram pass, all-reduce, Cholesky, apply) is enqueued before
     the verdict of call i is read; a rejected matrix (cond 1e9: shifted Cholesky QR) takes the ladder inside the loop on all ranks

@@ -1641,16 +1641,28 @@ struct ChainArgs {
 	const double* part; int nparts;      // Gram partials of the call being factored
 	unsigned* ticket;                    // arrival counter, zero at launch; the last adder re-arms it
 	int nred;                            // reduction workgroups = entries / 16
+	int direct;                          // 1: chol.gsum holds the reduced (row-partitioned: all-reduced) matrix already -- ONE chain workgroup,
+	                                     // which factors at once (nred, part, ticket unused)
 };
 __global__ __launch_bounds__(256, 2) void gram_blk_chain_kernel(const GramArgs a, const ChainArgs ch) {
 	extern __shared__ __attribute__((aligned(16))) float gb_as[];
 	static_assert(GB_LDS_BYTES >= (int)sizeof(double) * (64 * 65 + 4 * 256 + 128), "chol_body4's arrays alias the block buffers");
 	announce_previous_call(a.announce, a.announce_seq);
-	if ((int)blockIdx.x >= ch.nred) {
-		gram_blk_body(a, gb_as, (int)blockIdx.x - ch.nred, (int)gridDim.x - ch.nred);
+	const int nchain = ch.direct ? 1 : ch.nred;
+	if ((int)blockIdx.x >= nchain) {
+		gram_blk_body(a, gb_as, (int)blockIdx.x - nchain, (int)gridDim.x - nchain);
 		return;
 	}
 	const CholArgs& c = ch.chol;
+	if (ch.direct) {
+		// row-partitioned stream: the all-reduce sits between the reduction and this point, so only the factorisation rides along
+		const double rows = c.rows_dev ? c.rows_dev[0] : c.rows;
+		const float max_scond = fminf(128.0f, fmaxf(c.scond_floor, 0.12f * sqrtf((float)rows)));
+		const double* g = c.gsum;
+		chol_body4(c.r, c.ldr, c.z, c.status, c.host_status, [&](int e) { return g[e]; }, c.n, c.NT, /*f32_layout=*/1, 0.03125f, max_scond, 0.0,
+		           rows * 0x1p-90, reinterpret_cast<double*>(gb_as));
+		return;
+	}
 	gram_reduce1_body<true>(blockIdx.x, reinterpret_cast<double (*)[17]>(gb_as), const_cast<double*>(c.gsum), ch.part, ch.nparts, 10 * 256, c.rows,
 	                        nullptr, 0, nullptr, 0);
 	// The sums left as device-scope write-through stores; once they are acknowledged (vmcnt) the workgroup takes its ticket.  No

@@ -1441,10 +1441,136 @@ static int stream_of_calls_chained(int count, int mode, int reorth, float* q, si
 	return TSQR_MI_SUCCESS;
 }
 
+// The chained schedule of a ROW-PARTITIONED stream (every rank: a full 64-column block of 128 k <= 2^20 rows).  The all-reduce sits inside
+// the R-factor chain, so only the factorisation can ride in the next call's Gram launch (gram_blk_chain_kernel, `direct`):
+//     gram(0) reduce(0) allreduce(0) | [chol(0) + gram(1)]  reduce(1) allreduce(1)  apply(0) | [chol(1) + gram(2)]  reduce(2) allreduce(2)  apply(1) | ...
+//     ... | chol(last) (a launch of its own)  apply(last)
+// -- the Cholesky launch (17.5 us + its ramp) leaves the critical path of every call but the last.  The collectives are enqueued in a
+// different order than by the plain stream (allreduce(i + 1) before apply(i)), so ALL ranks must take this schedule or none: the
+// ranks agree by one all-reduce of their eligibility flags per loop call.  Returns -2 (nothing but that agreement enqueued) when any
+// rank is not eligible.  A rejected verdict -- the same on every rank -- drains the stream and finishes the count with blocking calls.
+static int stream_of_calls_dist_chained(const CallEnv& env, int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                                        size_t m, size_t n, void* wq_v, void* wr_v, void* stream) {
+	const int engine = engine_of(mode);
+	if (engine < 0 || m == 0 || n == 0 || env.nranks < 1) return -2;       // (the plain path reports these)
+	Ctx c;
+	env_ctx(c, env, wq_v, wr_v, m, n, nullptr, stream, /*keep_in_flight=*/false);
+	const bool mine = !reorth && n == PW && m % 128 == 0 && m <= ((size_t)1 << 20) && lda % 4 == 0 && lda <= ((size_t)1 << 24) && lda >= m && ldq >= m &&
+	                  ldr >= n && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug;
+	{
+		double h = mine ? 1.0 : 0.0;
+		HIPCHK(hipMemcpyAsync(c.gsum(), &h, sizeof(double), hipMemcpyHostToDevice, c.st));
+		HIPCHK(hipStreamSynchronize(c.st));              // (h is a stack variable)
+		if (c.comm.allreduce_f64(c.gsum(), 1, c.st)) { t_last_error = "all-reduce of the schedule flags failed"; return -1; }
+		HIPCHK(hipMemcpyAsync(&h, c.gsum(), sizeof(double), hipMemcpyDeviceToHost, c.st));
+		HIPCHK(hipStreamSynchronize(c.st));
+		if (h != (double)env.nranks) return -2;
+	}
+	c.fold_cor = (engine == 1);
+	static DevOnce attr;
+	if (attr.need(c.dev)) {
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES));
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES));
+		attr.done(c.dev);
+	}
+	const GramPlan g = gram_plan(m, n);
+	const int nchunks = (int)(m / 128), nparts = std::min(nchunks, g.nblocks), nelem = 10 * 256;
+	double* part = reinterpret_cast<double*>(c.wr);
+	volatile unsigned* words = reinterpret_cast<volatile unsigned*>(c.hsig.host);
+	unsigned seq[2] = {0, 0};
+	unsigned* announce = nullptr; unsigned announce_seq = 0;
+	auto gram_args = [&]() {
+		tsqrmi::GramArgs ga{};
+		ga.a = a; ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = nchunks; ga.cpw = g.cpw; ga.nwaves = g.nwaves; ga.part = part;
+		ga.announce = announce; ga.announce_seq = announce_seq; announce = nullptr;
+		return ga;
+	};
+	auto chol_args = [&](int i) {
+		tsqrmi::CholArgs ca{};
+		ca.r = r; ca.ldr = ldr; ca.z = c.wq + c.L.z;
+		ca.status = c.status_dev(i & 1);
+		ca.host_status = c.hsig.dev + 4 * (i & 1);
+		ca.gsum = c.gsum();
+		ca.rows_dev = c.gsum() + nelem;                  // the all-reduced row count (as chol_from_g)
+		ca.rows = c.rows_global;
+		ca.n = (int)n; ca.NT = 4; ca.level = 2; ca.scond_floor = g_set.bf16_scond_floor;
+		return ca;
+	};
+	auto reduce_allreduce = [&]() -> int {               // partials of the Gram pass just enqueued -> summed tiles + row count, over all ranks
+		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, c.gsum(), part, nparts, nelem, (double)m,
+		                   nullptr, (size_t)0, nullptr, 0);
+		HIPCHK(hipGetLastError());
+		if (c.comm.allreduce_f64(c.gsum(), (size_t)nelem + 1, c.st)) { t_last_error = "all-reduce of the Gram tiles failed"; return -1; }
+		return 0;
+	};
+	auto step = [&](int i) -> int {
+		if (i + 1 < count) {
+			tsqrmi::ChainArgs ch{};
+			ch.chol = chol_args(i); ch.direct = 1;
+			hipLaunchKernelGGL(tsqrmi::gram_blk_chain_kernel, dim3(1 + nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(), ch);
+			HIPCHK(hipGetLastError());
+			const int rc = reduce_allreduce();
+			if (rc) return rc;
+		} else {
+			if (announce) { hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, announce, announce_seq); announce = nullptr; }
+			hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, chol_args(i));
+			HIPCHK(hipGetLastError());
+		}
+		c.slot = i & 1;
+		const int rc = apply_rinv(c, engine, q, ldq, a, lda, r, ldr, m, n, /*z_ready=*/true, c.status_dev(i & 1));
+		if (rc) return rc;
+		unsigned sq = ++g_seq;
+		if (sq == 0) sq = ++g_seq;
+		seq[i & 1] = sq;
+		words[4 * (i & 1) + 3] = 0;
+		if (i + 1 < count) { announce = c.hsig.dev + 4 * (i & 1) + 3; announce_seq = sq; }   // raised by the chained launch of step i + 1
+		else hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, c.hsig.dev + 4 * (i & 1) + 3, sq);
+		HIPCHK(hipGetLastError());
+		return 0;
+	};
+	hipLaunchKernelGGL(tsqrmi::gram_blk_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args());
+	HIPCHK(hipGetLastError());
+	int rc = reduce_allreduce();
+	if (!rc) rc = step(0);
+	if (rc) return rc;
+	for (int i = 0; i < count; i++) {
+		if (i + 1 < count) { rc = step(i + 1); if (rc) return rc; }
+		for (bool done = false; !done;) {
+			for (int k = 0; k < 20000 && !done; k++) {
+				done = (words[4 * (i & 1) + 3] == seq[i & 1]);
+				if (!done) __builtin_ia32_pause();
+			}
+			if (!done) {
+				const hipError_t e = hipStreamQuery(c.st);
+				if (e == hipSuccess) done = true;
+				else if (e != hipErrorNotReady) HIPCHK(e);
+			}
+		}
+		if (words[4 * (i & 1)] != 0) {
+			// rejected on every rank alike (the verdict comes from the all-reduced matrix): drain -- the collectives enqueued ahead are the
+			// same on all ranks --, then this call and the rest as blocking calls with their whole ladder
+			HIPCHK(hipStreamSynchronize(c.st));
+			for (int k = i; k < count; k++) {
+				Ctx cc;
+				cc.comm = env.comm;
+				const int st = qr_dist_common(cc, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, env.nranks, stream);
+				if (st) return st;
+			}
+			return TSQR_MI_SUCCESS;
+		}
+	}
+	t_last_engine = 3;
+	return TSQR_MI_SUCCESS;
+}
+
 static int stream_of_calls(const CallEnv& env, int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                            size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
 	if (!env.dist && g_set.loop_depth.load() >= 3) {
 		const int st = stream_of_calls_chained(count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
+		if (st != -2) return st;
+	}
+	if (env.dist && g_set.loop_depth.load() >= 3 && count >= 3) {      // (conditions every rank shares; the rest is agreed on inside)
+		const int st = stream_of_calls_dist_chained(env, count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, stream);
 		if (st != -2) return st;
 	}
 	tsqr_mi_ticket tk[2];
