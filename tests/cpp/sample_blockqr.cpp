@@ -3,6 +3,7 @@
 // Prints residual and orthogonality; exit code 0 when both are within tolerance.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 #include <tsqr/blockqr.hpp>
@@ -58,8 +59,50 @@ int run(const std::size_t M, const std::size_t N) {
 	        residual < (f16 ? 1e-3 : 5e-7) && orthogonality < (f16 ? 5e-3 : 5e-6)) ? 0 : 1;      // (fp16: the rounding of Q and R to half)
 }
 
+// mtk::qr::qr_submit / qr_finish (not in the reference: include/tsqr/blockqr.hpp): two different matrices in flight through ONE buffer,
+// their factors compared bit for bit with those of the blocking call
+template <mtk::qr::compute_mode compute_mode>
+int run_two_in_flight(const std::size_t M, const std::size_t N) {
+	std::mt19937 mt(1);
+	std::uniform_real_distribution<float> dist(-1.0f, 1.0f);
+	std::vector<float> h_a[2], h_q[2], h_r[2], h_qb(M * N), h_rb(N * N);
+	float *d_a[2], *d_q[2], *d_r[2], *d_qb, *d_rb;
+	for (int k = 0; k < 2; k++) {
+		h_a[k].resize(M * N); h_q[k].resize(M * N); h_r[k].resize(N * N);
+		for (auto& v : h_a[k]) v = dist(mt);
+		hipMalloc((void**)&d_a[k], sizeof(float) * M * N); hipMalloc((void**)&d_q[k], sizeof(float) * M * N); hipMalloc((void**)&d_r[k], sizeof(float) * N * N);
+		hipMemcpy(d_a[k], h_a[k].data(), sizeof(float) * M * N, hipMemcpyHostToDevice);
+		hipMemset(d_r[k], 0, sizeof(float) * N * N);
+	}
+	hipMalloc((void**)&d_qb, sizeof(float) * M * N); hipMalloc((void**)&d_rb, sizeof(float) * N * N);
+	mtk::qr::buffer<compute_mode, false> buffer;
+	buffer.allocate(M, N);
+	hipStream_t stream;
+	hipStreamCreate(&stream);
+	mtk::qr::ticket t[2];
+	mtk::qr::qr_submit<compute_mode, false>(t[0], d_q[0], M, d_r[0], N, d_a[0], M, M, N, buffer, stream);
+	mtk::qr::qr_submit<compute_mode, false>(t[1], d_q[1], M, d_r[1], N, d_a[1], M, M, N, buffer, stream);
+	int bad = 0;
+	for (int k = 0; k < 2; k++) bad |= (mtk::qr::qr_finish(t[k]) != mtk::qr::success_factorization);
+	for (int k = 0; k < 2; k++) {
+		hipMemcpy(h_q[k].data(), d_q[k], sizeof(float) * M * N, hipMemcpyDeviceToHost);
+		hipMemcpy(h_r[k].data(), d_r[k], sizeof(float) * N * N, hipMemcpyDeviceToHost);
+		hipMemset(d_rb, 0, sizeof(float) * N * N);
+		bad |= (mtk::qr::qr<compute_mode, false>(d_qb, M, d_rb, N, d_a[k], M, M, N, buffer, stream) != mtk::qr::success_factorization);
+		hipMemcpy(h_qb.data(), d_qb, sizeof(float) * M * N, hipMemcpyDeviceToHost);
+		hipMemcpy(h_rb.data(), d_rb, sizeof(float) * N * N, hipMemcpyDeviceToHost);
+		bad |= (std::memcmp(h_qb.data(), h_q[k].data(), sizeof(float) * M * N) != 0) | (std::memcmp(h_rb.data(), h_r[k].data(), sizeof(float) * N * N) != 0);
+	}
+	std::printf("mode=%d two calls in flight (qr_submit / qr_finish) %zu x %zu: %s\n", (int)compute_mode, M, N, bad ? "MISMATCH" : "the blocking call's bits");
+	for (int k = 0; k < 2; k++) { hipFree(d_a[k]); hipFree(d_q[k]); hipFree(d_r[k]); }
+	hipFree(d_qb); hipFree(d_rb); hipStreamDestroy(stream);
+	return bad;
+}
+
 int main() {
 	int rc = 0;
+	rc |= run_two_in_flight<mtk::qr::compute_mode::fp32_tc_cor>(20000, 64);
+	rc |= run_two_in_flight<mtk::qr::compute_mode::fp32_notc>(30000, 128);
 	rc |= run<mtk::qr::compute_mode::fp32_tc_cor, false>(9211, 51);
 	rc |= run<mtk::qr::compute_mode::fp32_notc, false>(9211, 51);
 	rc |= run<mtk::qr::compute_mode::fp32_tc_cor, true>(2000, 100);
