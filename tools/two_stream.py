@@ -51,19 +51,48 @@ def two_streams(k, S, H):
         apply(i, S); e_apply[i].record(S)
 
 
-for name in ("one stream", "two streams"):
+def free_cu_streams(k, S, H):
+    """S: Gram pass + reduction of call i + 1, then the apply pass of call i; H: only the Cholesky launches -- with grids that leave ONE CU
+    free (tsqr_mi_set_tuning2), so that the one-workgroup factorisation can run beside the passes instead of behind them"""
+    eg = [torch.cuda.Event() for _ in range(k + 2)]
+    ec = [torch.cuda.Event() for _ in range(k + 2)]
+    ea = [torch.cuda.Event() for _ in range(k + 2)]
+    def G(i):
+        b = bfs[i & 1]
+        assert L.tsqr_mi_gram_f32(2, None, a.data_ptr(), m, m, n, b.dwq.data_ptr(), b.dwr.data_ptr(), S.cuda_stream) == 0
+        eg[i].record(S)
+    def C(i):
+        b = bfs[i & 1]
+        H.wait_event(eg[i])
+        if i >= 2:
+            H.wait_event(ea[i - 2])                 # Z of this work set was read by apply(i - 2)
+        assert L.tsqr_mi_chol_f32(2, rs[i & 1].data_ptr(), n, None, m, n, b.dwq.data_ptr(), None, H.cuda_stream) == 0
+        ec[i].record(H)
+    G(0); C(0)
+    for i in range(k):
+        if i + 1 < k:
+            G(i + 1); C(i + 1)
+        S.wait_event(ec[i])
+        apply(i, S); ea[i].record(S)
+
+
+for name in ("one stream", "two streams", "Cholesky on a second stream, one CU left free by the passes", "one stream, one CU left free"):
     S, H = torch.cuda.Stream(), torch.cuda.Stream()
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if name == "one stream":
+        if name.endswith("left free by the passes") or name.endswith("one CU left free"):
+            L.tsqr_mi_set_tuning2(2040, 4080)      # 510 Gram workgroups (two per CU on 255 CUs), 1020 apply workgroups (four per CU on 255)
+        if name.startswith("one stream"):
             one_stream(calls)
-        else:
+        elif name == "two streams":
             two_streams(calls, S, H)
+        else:
+            free_cu_streams(calls, S, H)
         t_host = time.perf_counter() - t0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print("%-11s %d calls of %d x %d %s: %.2f us per call (host enqueue %.2f us per call)" % (name, calls, m, n, mode.name, dt / calls * 1e6, t_host / calls * 1e6))
+        print("%-60s %d calls of %d x %d %s: %.2f us per call (host enqueue %.2f us per call)" % (name, calls, m, n, mode.name, dt / calls * 1e6, t_host / calls * 1e6))
 # sanity: Q^T Q = I
 qq = q.double() @ q.double().T
 print("orth %.3e" % float((qq - torch.eye(n, device="cuda", dtype=torch.float64)).norm()))
