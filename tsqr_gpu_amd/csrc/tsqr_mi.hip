@@ -1228,8 +1228,6 @@ int tsqr_mi_qr_f32(int mode, int reorth, float* q, size_t ldq, float* r, size_t 
 
 // ---- submit / finish: the first attempt of a call (bf16-split Gram level, everything speculative) is enqueued and the host returns;
 // finish reads the verdict and, for a rejected matrix, runs the rest of the ladder as the blocking call does (include/tsqr_mi.h) ----
-// own_flag: a one-thread completion kernel behind the attempt (the public entry: always).  The loop entry leaves it out for every call
-// but the last and lets the NEXT call's first kernel raise the word instead (`announce`: the ticket submitted just before this one).
 // CallEnv: what a row-partitioned call adds to the arguments (its collectives); env.dist == false: the single-GPU call.
 struct CallEnv { bool dist = false; Comm comm; int nranks = 1; };
 static void env_ctx(Ctx& c, const CallEnv& env, void* wq_v, void* wr_v, size_t m, size_t n, unsigned* h_wl, void* stream, bool keep_in_flight) {
@@ -1245,6 +1243,8 @@ static void env_ctx(Ctx& c, const CallEnv& env, void* wq_v, void* wr_v, size_t m
 		resolve_host_sig(c, h_wl, m);
 	}
 }
+// own_flag: a one-thread completion kernel behind the attempt (the public entry: always).  The loop entries leave it out for every call
+// but the last and let the NEXT call's first kernel raise the word instead (`announce`: the ticket submitted just before this one).
 static int submit_impl(const CallEnv& env, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                        size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream, tsqr_mi_ticket* t,
                        tsqr_mi_ticket* announce, bool own_flag) {
