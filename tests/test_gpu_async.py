@@ -170,7 +170,7 @@ def test_submit_error_paths(bq, torch_cuda):
         bq.submit(d, 8, d, 8, d, 8, 8, 8, bf, mode=bq.compute_mode.fp16_notc)
 
 
-@pytest.mark.parametrize("m,n,kind", [(1 << 17, 64, "uniform"), (1 << 15, 64, "cond1e6"), (30000, 64, "cond1e6"), (50000, 128, "uniform"), (400000, 12, "geo45")])
+@pytest.mark.parametrize("m,n,kind", [(1 << 17, 64, "uniform"), (1 << 15, 64, "cond1e6"), (30000, 64, "cond1e6"), (1 << 17, 128, "uniform"), (50000, 128, "uniform"), (400000, 12, "geo45")])
 def test_loop_entry_depths_agree(bq, oracle, torch_cuda, m, n, kind):
     """tsqr_mi_qr_f32_loop with two calls in flight against the same loop of blocking calls: same outputs, same engine."""
     md = bq.compute_mode.fp32_tc_cor
@@ -198,7 +198,7 @@ def test_loop_entry_depths_agree(bq, oracle, torch_cuda, m, n, kind):
 
 
 @pytest.mark.parametrize("count", [1, 2, 3, 8])
-@pytest.mark.parametrize("m,n", [(1 << 16, 64), (9211, 51), (20000, 128), (20000, 100)])
+@pytest.mark.parametrize("m,n", [(1 << 16, 64), (9211, 51), (20000, 128), (20000, 100), (1 << 16, 128), (64 * 700, 128)])
 def test_loop_counts(bq, oracle, torch_cuda, m, n, count):
     """Inside the loop a call's completion word is raised by the first kernel of the call behind it (every Gram kernel form: block
     pattern, chunked, 128-column fast and general), the last call by a completion kernel of its own: any count ends complete."""

@@ -173,3 +173,33 @@ def test_chained_launch_against_the_launches_it_merges(st, m, kind):
         assert np.array_equal(st3[0, :2], st3[1, :2])
         assert abs(float(st3[0, 2:3].view(np.float32)[0]) - float(st3[1, 2:3].view(np.float32)[0])) <= 1e-5 * abs(float(st3[0, 2:3].view(np.float32)[0]))
     assert st3[0, 0] == (0 if kind == "uniform" else 1)
+
+
+@pytest.mark.parametrize("m,kind", [(1 << 16, "uniform"), (1 << 20, "uniform"), (64 * 300, "uniform"), (1 << 16, "correlated")])
+def test_wide_chained_launch_against_the_launches_it_merges(st, m, kind):
+    """gram_wide_chain_kernel (a stream of 128-column calls): its chain role -- the two-block factorisation on four waves of workgroup 0,
+    chol_wide4_body -- against chol_wide_kernel on the same summed tiles (R, the 128 x 128 Z, the verdict), its Gram role against
+    gram_wide_kernel (partials bit for bit)."""
+    L, torch = st
+    L.tsqr_selftest_wide_chain.restype = ctypes.c_int
+    L.tsqr_selftest_wide_chain.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    a = torch.rand(128, m, generator=g, device="cuda") * 2 - 1
+    if kind == "correlated":                                              # rejected: the verdict words agree as well
+        a = a * 0.05 + a[:1]
+    nwg = min(m // 64, 256)
+    r3 = torch.full((3, 128, 128), float("nan"), device="cuda")
+    zw3 = torch.full((3, 128, 128), float("nan"), device="cuda")
+    st3 = torch.full((3, 16), 77, dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(2 * nwg * 36 * 256 + 36 * 256 + 16 + (3 * 2 * 4096) // 2 + 64, dtype=torch.float64, device="cuda")
+    eq = ctypes.c_int(-1)
+    rc = L.tsqr_selftest_wide_chain(a.data_ptr(), m, m, nwg, r3.data_ptr(), zw3.data_ptr(), st3.data_ptr(), scratch.data_ptr(), ctypes.byref(eq))
+    assert rc == 0 and eq.value == 1
+    r3, zw3, st3 = r3.cpu().numpy(), zw3.cpu().numpy(), st3.cpu().numpy()
+    assert st3[0, 0] == st3[1, 0] == (0 if kind == "uniform" else 1)
+    if kind == "uniform":
+        assert np.array_equal(r3[0], r3[1]) and np.array_equal(zw3[0], zw3[1])
+        assert st3[0, 1] == st3[1, 1]                                     # smallest pivot ratio: the same bits
+        s0, s1 = float(st3[0, 2:3].view(np.float32)[0]), float(st3[1, 2:3].view(np.float32)[0])
+        assert abs(s0 - s1) <= 1e-5 * abs(s0)                             # (S is added up in another order)

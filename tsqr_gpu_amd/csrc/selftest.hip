@@ -4,6 +4,7 @@
 #include <cstring>
 #include <vector>
 #include "tsqr_kernels.hip"
+#include "tsqr_wide.hip"
 
 namespace {
 using namespace tsqrmi;
@@ -174,6 +175,39 @@ extern "C" int tsqr_selftest_apply_balance(float* q, const float* a, size_t ld, 
 	aa.share[0] = s0; aa.share[1] = s1; aa.share[2] = s2; aa.share[3] = s3; aa.even_share = even_share;
 	for (int i = 0; i <= warm; i++) hipLaunchKernelGGL(apply_stamp_kernel, dim3(nwg), dim3(256), lds, 0, aa, stamps);
 	return (int)hipDeviceSynchronize();
+}
+
+// ---- gram_wide_chain_kernel against the launches it merges (a stream of 128-column calls): m x 128 matrix a (m % 64 == 0).
+// [0]: gram_wide_kernel<true> -> gram_reduce1_kernel -> chol_wide_kernel.  [1]: the chain role of a fused launch on the same summed
+// tiles (its Gram role writes a second set of partials, compared bitwise with the first).  r3: 3 x 128 x 128, zw3: 3 x 128 x 128,
+// status3: 3 x 16 words; scratch: 2 * nwg * 36 * 256 + 36 * 256 + 16 doubles + 3 * 2 * 4096 floats + 64 words.
+extern "C" int tsqr_selftest_wide_chain(const float* a, size_t lda, size_t m, int nwg, float* r3, float* zw3, unsigned* status3, double* scratch, int* part_equal_host) {
+	const int nelem = 36 * 256;
+	double* partA = scratch; double* partB = partA + (size_t)nwg * nelem;
+	double* gsum = partB + (size_t)nwg * nelem;
+	float* zf = reinterpret_cast<float*>(gsum + nelem + 16);
+	unsigned* st12 = reinterpret_cast<unsigned*>(zf + 3 * 2 * 4096);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GW_LDS_BYTES);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_wide_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GWC_LDS_BYTES);
+	tsqrmi::GramWideArgs ga{};
+	ga.a = a; ga.lda = lda; ga.m = m; ga.n = 128; ga.blk0 = 0; ga.nblk = (int)(m / 64); ga.part = partA;
+	auto cw = [&](int k) {
+		tsqrmi::CholWideArgs c{};
+		c.gsum = gsum; c.r = r3 + 16384 * k; c.ldr = 128; c.n = 128; c.zf1 = zf + 8192 * k; c.zf2 = zf + 8192 * k + 4096; c.zw = zw3 + 16384 * k;
+		c.st1 = st12 + 32 * k; c.st2 = st12 + 32 * k + 16; c.status = status3 + 16 * k; c.rows = (double)m; c.scond_floor = 4.0f;
+		return c;
+	};
+	hipLaunchKernelGGL(tsqrmi::gram_wide_kernel<true>, dim3(nwg), dim3(512), tsqrmi::GW_LDS_BYTES, 0, ga);
+	hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, 0, gsum, partA, nwg, nelem, (double)m, nullptr, (size_t)0, nullptr, 0);
+	hipLaunchKernelGGL(tsqrmi::chol_wide_kernel, dim3(1), dim3(1024), 0, 0, cw(0));
+	ga.part = partB;
+	hipLaunchKernelGGL(tsqrmi::gram_wide_chain_kernel, dim3(1 + nwg), dim3(512), tsqrmi::GWC_LDS_BYTES, 0, ga, cw(1));
+	if (hipDeviceSynchronize() != hipSuccess) return -1;
+	std::vector<double> ha((size_t)nwg * nelem), hb((size_t)nwg * nelem);
+	(void)hipMemcpy(ha.data(), partA, ha.size() * 8, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(hb.data(), partB, hb.size() * 8, hipMemcpyDeviceToHost);
+	*part_equal_host = memcmp(ha.data(), hb.data(), ha.size() * 8) == 0 ? 1 : 0;
+	return (int)hipGetLastError();
 }
 
 // ---- in-kernel time stamps of chol16_kernel (this library is built with -DTSQR_CHOL_STAMPS): out[4][160] shader-clock values ----

@@ -178,7 +178,9 @@ GramPlan gram_plan(size_t m, size_t n) {
 // [summed tiles 36*256 + row count (+pad)] | [Z 128 x 128 fp32][Z22 fp32 4096]
 constexpr size_t WIDE_G_DOUBLES = 36 * 256 + 8;
 constexpr size_t WIDE_OFF_ZW = 2 * WIDE_G_DOUBLES, WIDE_OFF_ZF2 = WIDE_OFF_ZW + 128 * 128, WIDE_FLOATS = WIDE_OFF_ZF2 + 4096;
-constexpr int WIDE_MAX_WGS = 256;                       // gram_wide_kernel: one eight-wave workgroup per CU
+constexpr int WIDE_MAX_WGS = 255;                       // gram_wide_kernel: one eight-wave workgroup per CU -- on 255 of the 256 CUs: in a stream of calls the
+                                                        // last CU holds the factorisation of the call before (gram_wide_chain_kernel), and the partials must
+                                                        // be those of the blocking call
 inline size_t wide_part_floats(size_t m) { return (std::min<size_t>((m + 63) / 64, WIDE_MAX_WGS) + 1) * 36 * 256 * 2; }
 
 // layout of wq (floats): [stack_b][Z: 4096][S: 4096][R1 copy: n*n][R2: n*n][r3, r4: 4096 each][summed tiles + row count][status]
@@ -1441,6 +1443,109 @@ static int stream_of_calls_chained(int count, int mode, int reorth, float* q, si
 	return TSQR_MI_SUCCESS;
 }
 
+// The chained schedule for a stream of 128-column calls (one GPU; every 64-row block full: m % 64 == 0, the fast Gram form): the
+// two-block factorisation of call i (45 us on one workgroup) rides in the Gram launch of call i + 1 (gram_wide_chain_kernel); the
+// reduction of the partials stays a launch of its own in front of it:
+//     gram(0) reduce(0) | [chol(0) + gram(1)]  reduce(1)  apply(0) | [chol(1) + gram(2)]  reduce(2)  apply(1) | ... | chol(last)  apply(last)
+// Returns -2 when the call is not one for it (nothing enqueued); a rejected verdict drains the stream and finishes the count with
+// blocking calls (which fall back to 64-column panels and overwrite A, as the blocking call does).
+static int stream_of_calls_wide_chained(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
+                                        size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
+	const int engine = engine_of(mode);
+	if (count < 3 || engine < 0 || reorth || n != 2 * PW || m < n || m % 64 != 0 || m / 64 < 2 * (size_t)WIDE_MAX_WGS || lda > ((size_t)1 << 23) ||
+	    lda < m || ldq < m || ldr < n || lda % 4 != 0 || (reinterpret_cast<uintptr_t>(a) & 15) != 0)
+		return -2;
+	Ctx c;
+	init_ctx(c, wq_v, wr_v, m, n, stream);
+	c.rows_global = (double)m;
+	resolve_host_sig(c, h_wl, m);
+	if (!(c.wide && c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug)) return -2;
+	static DevOnce attr;
+	if (attr.need(c.dev)) {
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GW_LDS_BYTES));
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_wide_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GWC_LDS_BYTES));
+		attr.done(c.dev);
+	}
+	float* w = c.wq + c.L.wide;
+	double* gsum = reinterpret_cast<double*>(w);
+	float* zw = w + WIDE_OFF_ZW;
+	float* zf2 = w + WIDE_OFF_ZF2;
+	const int nblk = (int)(m / 64), wgs = WIDE_MAX_WGS, nelem = 36 * 256;
+	double* part = reinterpret_cast<double*>(c.wr);
+	volatile unsigned* words = reinterpret_cast<volatile unsigned*>(c.hsig.host);
+	unsigned seq[2] = {0, 0};
+	unsigned* announce = nullptr; unsigned announce_seq = 0;
+	auto gram_args = [&]() {
+		tsqrmi::GramWideArgs ga{};
+		ga.a = a; ga.lda = lda; ga.m = m; ga.n = (int)n; ga.blk0 = 0; ga.nblk = nblk; ga.part = part;
+		ga.announce = announce; ga.announce_seq = announce_seq; announce = nullptr;
+		return ga;
+	};
+	auto chol_args = [&](int i) {
+		tsqrmi::CholWideArgs wa{};
+		wa.gsum = gsum; wa.r = r; wa.ldr = ldr; wa.n = (int)n; wa.zf1 = c.wq + c.L.z; wa.zf2 = zf2; wa.zw = zw;
+		wa.st1 = c.status_dev(2); wa.st2 = c.status_dev(3); wa.status = c.status_dev(i & 1);
+		wa.host_status = c.hsig.dev + 4 * (i & 1);
+		wa.rows = (double)m; wa.scond_floor = g_set.bf16_scond_floor;
+		return wa;
+	};
+	auto reduce = [&]() {
+		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, gsum, part, wgs, nelem, (double)m, nullptr, (size_t)0, nullptr, 0);
+	};
+	auto step = [&](int i) -> int {
+		if (i + 1 < count) {
+			hipLaunchKernelGGL(tsqrmi::gram_wide_chain_kernel, dim3(1 + wgs), dim3(512), tsqrmi::GWC_LDS_BYTES, c.st, gram_args(), chol_args(i));
+			reduce();
+		} else {
+			if (announce) { hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, announce, announce_seq); announce = nullptr; }
+			hipLaunchKernelGGL(tsqrmi::chol_wide_kernel, dim3(1), dim3(1024), 0, c.st, chol_args(i));
+		}
+		HIPCHK(hipGetLastError());
+		tsqrmi::ApplyArgs aa{};
+		aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = zw; aa.skip_status = c.status_dev(i & 1);
+		const int rc = (engine == 0) ? launch_apply_wide<0>(c, aa) : (engine == 1 ? launch_apply_wide<1>(c, aa) : launch_apply_wide<2>(c, aa));
+		if (rc) return rc;
+		HIPCHK(hipGetLastError());
+		unsigned sq = ++g_seq;
+		if (sq == 0) sq = ++g_seq;
+		seq[i & 1] = sq;
+		words[4 * (i & 1) + 3] = 0;
+		if (i + 1 < count) { announce = c.hsig.dev + 4 * (i & 1) + 3; announce_seq = sq; }
+		else hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, c.hsig.dev + 4 * (i & 1) + 3, sq);
+		HIPCHK(hipGetLastError());
+		return 0;
+	};
+	hipLaunchKernelGGL((tsqrmi::gram_wide_kernel<true>), dim3(wgs), dim3(512), tsqrmi::GW_LDS_BYTES, c.st, gram_args());
+	reduce();
+	HIPCHK(hipGetLastError());
+	int rc = step(0);
+	if (rc) return rc;
+	for (int i = 0; i < count; i++) {
+		if (i + 1 < count) { rc = step(i + 1); if (rc) return rc; }
+		for (bool done = false; !done;) {
+			for (int k = 0; k < 20000 && !done; k++) {
+				done = (words[4 * (i & 1) + 3] == seq[i & 1]);
+				if (!done) __builtin_ia32_pause();
+			}
+			if (!done) {
+				const hipError_t e = hipStreamQuery(c.st);
+				if (e == hipSuccess) done = true;
+				else if (e != hipErrorNotReady) HIPCHK(e);
+			}
+		}
+		if (words[4 * (i & 1)] != 0) {
+			HIPCHK(hipStreamSynchronize(c.st));
+			for (int k = i; k < count; k++) {
+				const int st = tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, nullptr, nullptr, h_wl, stream);
+				if (st) return st;
+			}
+			return TSQR_MI_SUCCESS;
+		}
+	}
+	t_last_engine = 5;
+	return TSQR_MI_SUCCESS;
+}
+
 // The chained schedule of a ROW-PARTITIONED stream (every rank: a full 64-column block of 128 k <= 2^20 rows).  The all-reduce sits inside
 // the R-factor chain, so only the factorisation can ride in the next call's Gram launch (gram_blk_chain_kernel, `direct`):
 //     gram(0) reduce(0) allreduce(0) | [chol(0) + gram(1)]  reduce(1) allreduce(1)  apply(0) | [chol(1) + gram(2)]  reduce(2) allreduce(2)  apply(1) | ...
@@ -1566,7 +1671,9 @@ static int stream_of_calls_dist_chained(const CallEnv& env, int count, int mode,
 static int stream_of_calls(const CallEnv& env, int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                            size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
 	if (!env.dist && g_set.loop_depth.load() >= 3) {
-		const int st = stream_of_calls_chained(count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
+		int st = stream_of_calls_chained(count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
+		if (st != -2) return st;
+		st = stream_of_calls_wide_chained(count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
 		if (st != -2) return st;
 	}
 	if (env.dist && g_set.loop_depth.load() >= 3 && count >= 3) {      // (conditions every rank shares; the rest is agreed on inside)

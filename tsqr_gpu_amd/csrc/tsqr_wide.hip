@@ -116,10 +116,9 @@ __device__ __forceinline__ void gram_wide_step(f32x4 (&acc)[9], const unsigned* 
 // FAST: every block is full (64 rows inside the matrix, n == 128, 128 lda floats < 4 GiB).  !FAST: the general form (ragged rows, n < 128), one block in
 // flight -- the host sends only what FAST cannot take there.
 constexpr int GW_LDS_BYTES = 2 * 3 * 128 * GW_CS * 4;
+// (the body takes its workgroup number and the number of Gram workgroups as arguments: gram_wide_chain_kernel runs it on a part of its grid)
 template <bool FAST>
-__global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
-	extern __shared__ __attribute__((aligned(16))) unsigned gw_img[];    // [buffer][image hi / mid / lo][column][row pair]
-	announce_previous_call(a.announce, a.announce_seq);
+__device__ __forceinline__ void gram_wide_body(const GramWideArgs& a, unsigned* gw_img, const int wg, const int nwg) {
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the per-role MFMA sections are scalar branches
@@ -159,8 +158,8 @@ __global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
 			}
 		}
 	};
-	const int step = gridDim.x;
-	int bi = blockIdx.x, it = 0;
+	const int step = nwg;
+	int bi = wg, it = 0;
 	auto split_block = [&](const f32x4 (&v)[4], unsigned* buf) {
 		// split the block once: thread (column, four rows) -> two dwords per image
 #pragma unroll
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
 	}
 	__syncthreads();
 	if (ks == 0) {
-		double* out = a.part + (size_t)blockIdx.x * WIDE_TILES * 256;
+		double* out = a.part + (size_t)wg * WIDE_TILES * 256;
 #pragma unroll
 		for (int t = 0; t < 9; t++) {
 			const int ti = role == 0 ? wide_role_ti(0, t) : (role == 1 ? wide_role_ti(1, t) : (role == 2 ? wide_role_ti(2, t) : wide_role_ti(3, t)));
@@ -237,6 +236,12 @@ __global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
 			for (int r = 0; r < 4; r++) part_store(&out[(dst * 4 + r) * 64 + lane], tot[t][r] + red[((role * 9 + t) * 4 + r) * 64 + lane]);
 		}
 	}
+}
+template <bool FAST>
+__global__ __launch_bounds__(512) void gram_wide_kernel(const GramWideArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned gw_img[];    // [buffer][image hi / mid / lo][column][row pair]
+	announce_previous_call(a.announce, a.announce_seq);
+	gram_wide_body<FAST>(a, gw_img, blockIdx.x, gridDim.x);
 }
 
 // chol_wide_kernel: the whole two-block factorisation in ONE workgroup and one launch -- chol(G11), the Schur complement
@@ -401,6 +406,169 @@ __global__ __launch_bounds__(1024) void chol_wide_kernel(const CholWideArgs a) {
 			hs[0] = s0;
 		}
 	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two-block factorisation on FOUR waves, for the one place where it lives in a workgroup that is not its own launch: the chain role
+// of gram_wide_chain_kernel (a stream of 128-column calls, tsqr_mi_qr_f32_loop).  chol_wide_kernel's steps in its order, with its
+// arithmetic: chol_body4 for the two 64 x 64 factorisations (bitwise equal to chol_body16) and the same fp64-MFMA tile products,
+// wave w taking the tiles (0..3, w) one after the other instead of one tile per wave -- R and Z come out bit for bit as from
+// chol_wide_kernel (the sum S of the verdict is added up in another order).  LDS from the caller: WIDE4_LDS_DOUBLES doubles.
+// ---------------------------------------------------------------------------------------------
+constexpr int WIDE4_LDS_DOUBLES = (64 * 65 + 4 * 256 + 128) + 2 * 64 * 68 + 10 * 256 + 128 + 8 + 2;
+__device__ __forceinline__ void chol_wide4_body(const CholWideArgs& a, double* lds) {
+	double* Lc = lds;                                    // chol_body4's arrays; its first 64 * 65 doubles end up as the fp64 image of inverse(R)
+	double* Gd = Lc + (64 * 65 + 4 * 256 + 128);         // G12: Gd[k * 68 + j]; later Z11 by columns
+	double* Rs = Gd + 64 * 68;                           // R12; later T = R12 Z22
+	double* G2s = Rs + 64 * 68;                          // G22' in chol_body4's tile order, fp64 accumulator layout
+	double* dg = G2s + 10 * 256;                         // [128]
+	double* red = dg + 128;                              // [8]
+	unsigned* verdict = reinterpret_cast<unsigned*>(red + 8);
+	const int t = threadIdx.x;                           // 0 .. 255
+	const int n2 = a.n - 64, NT2 = (n2 + 15) / 16;
+	auto reject = [&]() {
+		if (t == 0) {
+			a.status[0] = 1u; a.status[1] = 0u; a.status[2] = 0u;
+			if (a.host_status) { volatile unsigned* hs = a.host_status; hs[1] = 0u; hs[2] = 0u; hs[0] = 1u; }
+		}
+	};
+	if (a.prev_status && a.prev_status[0] != 0) { reject(); return; }
+	const double rows = a.rows_dev ? a.rows_dev[0] : a.rows;
+	const double min_diag = rows * 0x1p-90;
+	const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+	const int tj = w, li = l & 15, lq = l >> 4;          // this wave's output tiles: (ti, w), ti = 0 .. 3
+	double gin[16], g2v[4][4], dgin = 0.0;
+#pragma unroll
+	for (int u = 0; u < 16; u++) gin[u] = a.gsum[WIDE_G12 + t + 256 * u];
+#pragma unroll
+	for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++) g2v[ti][reg] = (ti <= tj) ? a.gsum[WIDE_G22 + tri4(ti, tj) * 256 + lq * 64 + 16 * reg + li] : 0.0;
+	if (t < 128) {
+		const int blk = t >> 6, j = t & 63, d = j >> 4, cc = j & 15;
+		dgin = a.gsum[(blk ? WIDE_G22 : 0) + tri4(d, d) * 256 + (cc & 3) * 64 + 16 * (cc >> 2) + cc];
+	}
+	// ---- block 1 ----
+	double* Zi = Lc;
+	chol_body4(a.r, a.ldr, a.zf1, a.st1, nullptr, PtrLoad{a.gsum}, 64, 4, 1, 0.03125f, INFINITY, 0.0, min_diag, Lc);
+	if (t == 0) verdict[0] = a.st1[0];
+	if (t < 128) dg[t] = dgin;
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int e = t + 256 * u;
+		const int tile = e >> 8, reg = (e >> 6) & 3, ll = e & 63;
+		Gd[(16 * (tile >> 2) + 4 * (ll >> 4) + reg) * 68 + 16 * (tile & 3) + (ll & 15)] = gin[u];
+	}
+	__syncthreads();
+	if (verdict[0] != 0) { reject(); return; }
+	// ---- Schur complement ----
+#pragma unroll
+	for (int ti = 0; ti < 4; ti++) {
+		const f64x4 c = tile_product_f64([&](int k) { return Zi[(16 * ti + li) * 65 + k]; }, [&](int k) { return Gd[k * 68 + 16 * tj + li]; }, 0, 4 * (ti + 1), lq);
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++) {
+			const int i = 16 * ti + lq + 4 * reg, j = 16 * tj + li;
+			const double v = (j < n2) ? c[reg] : 0.0;
+			Rs[i * 68 + j] = v;
+			if (j < n2) a.r[(size_t)(64 + j) * a.ldr + i] = (float)v;
+		}
+	}
+	lds_barrier();
+	double* Cs = Gd;
+	for (int e = t; e < 64 * 64; e += 256) Cs[(e >> 6) * 68 + (e & 63)] = Zi[(e >> 6) * 65 + (e & 63)];
+#pragma unroll
+	for (int ti = 0; ti < 4; ti++) {
+		if (ti <= tj && tj < NT2) {
+			const f64x4 c = tile_product_f64([&](int i) { return Rs[i * 68 + 16 * ti + li]; }, [&](int i) { return Rs[i * 68 + 16 * tj + li]; }, 0, 16, lq);
+#pragma unroll
+			for (int reg = 0; reg < 4; reg++) G2s[(ti * NT2 - (ti * (ti - 1)) / 2 + (tj - ti)) * 256 + reg * 64 + l] = g2v[ti][reg] - c[reg];
+		}
+	}
+	lds_barrier();
+	// ---- block 2 ----
+	chol_body4(a.r + 64 * a.ldr + 64, a.ldr, a.zf2, a.st2, nullptr, PtrLoad{G2s}, n2, NT2, 0, 0.03125f, INFINITY, 0.0, min_diag, Lc);
+	if (t == 0) verdict[1] = a.st2[0];
+	__syncthreads();
+	if (verdict[1] != 0) { reject(); return; }
+	// ---- Z12, the 128 x 128 Z, the verdict ----
+	f64x4 tt[4];
+#pragma unroll
+	for (int ti = 0; ti < 4; ti++)
+		tt[ti] = tile_product_f64([&](int x) { return Rs[(16 * ti + li) * 68 + x]; }, [&](int x) { return Zi[(16 * tj + li) * 65 + x]; }, 0, 4 * (tj + 1), lq);
+	double s_acc = 0.0;
+	float ratio = 1.0f;
+	for (int e = t; e < 64 * 64; e += 256) {
+		const int j = e & 63, K = e >> 6;
+		const double z1 = Cs[K * 68 + j];
+		const double z2 = (K < n2) ? Zi[K * 65 + j] : 0.0;
+		s_acc = fma(dg[j] * z1, z1, s_acc);
+		s_acc = fma(dg[64 + j] * z2, z2, s_acc);
+		if (j == K) {
+			ratio = fminf(ratio, (float)(1.0 / (dg[j] * z1 * z1)));
+			if (K < n2) ratio = fminf(ratio, (float)(1.0 / (dg[64 + j] * z2 * z2)));
+		}
+		a.zw[(size_t)K * 128 + j] = (float)z1;
+		a.zw[(size_t)K * 128 + 64 + j] = 0.0f;
+		a.zw[(size_t)(64 + K) * 128 + 64 + j] = (float)z2;
+	}
+	lds_barrier();
+#pragma unroll
+	for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++) Rs[(16 * ti + lq + 4 * reg) * 68 + 16 * tj + li] = tt[ti][reg];
+	lds_barrier();
+#pragma unroll
+	for (int ti = 0; ti < 4; ti++) {
+		const f64x4 c = tile_product_f64([&](int k) { return Cs[k * 68 + 16 * ti + li]; }, [&](int k) { return Rs[k * 68 + 16 * tj + li]; }, 4 * ti, 16, lq);
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++) {
+			const int i = 16 * ti + lq + 4 * reg, y = 16 * tj + li;
+			const double zz = (y < n2) ? -c[reg] : 0.0;
+			a.zw[(size_t)(64 + y) * 128 + i] = (float)zz;
+			s_acc = fma(dg[i] * zz, zz, s_acc);
+		}
+	}
+	for (int e = t; e < 64 * n2; e += 256) {
+		const int i = e % n2, j = e / n2;
+		a.r[(size_t)j * a.ldr + 64 + i] = 0.0f;
+	}
+	for (int o = 32; o > 0; o >>= 1) { s_acc += __shfl_xor(s_acc, o); ratio = fminf(ratio, __shfl_xor(ratio, o)); }
+	if ((t & 63) == 0) { red[t >> 6] = s_acc; red[4 + (t >> 6)] = (double)ratio; }
+	lds_barrier();
+	if (t == 0) {
+		double ssum = 0.0;
+		float rmin = 1.0f;
+#pragma unroll
+		for (int k = 0; k < 4; k++) { ssum += red[k]; rmin = fminf(rmin, (float)red[4 + k]); }
+		const float scond = (float)(ssum / (double)a.n);
+		const float max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
+		const unsigned s0 = (rmin > 0.03125f && scond <= max_scond) ? 0u : 1u;
+		a.status[0] = s0;
+		a.status[1] = __builtin_bit_cast(unsigned, rmin);
+		a.status[2] = __builtin_bit_cast(unsigned, scond);
+		if (a.host_status) {
+			volatile unsigned* hs = a.host_status;
+			hs[1] = __builtin_bit_cast(unsigned, rmin);
+			hs[2] = __builtin_bit_cast(unsigned, scond);
+			hs[0] = s0;
+		}
+	}
+}
+
+// A stream of 128-column calls: workgroup 0 of the launch is the two-block factorisation of call i (its waves 4 .. 7 leave at once -- a
+// barrier counts the waves that are still there --, waves 0 .. 3 run chol_wide4_body in the LDS the Gram role stages its images
+// in), every other workgroup is the Gram pass of call i + 1, numbered from 0 as in gram_wide_kernel.  The reduction of a call's
+// partials stays a launch of its own in front (tsqr_mi.hip: stream_of_calls_wide_chained).
+constexpr int GWC_LDS_BYTES = (GW_LDS_BYTES > WIDE4_LDS_DOUBLES * 8) ? GW_LDS_BYTES : WIDE4_LDS_DOUBLES * 8;
+__global__ __launch_bounds__(512) void gram_wide_chain_kernel(const GramWideArgs a, const CholWideArgs cw) {
+	extern __shared__ __attribute__((aligned(16))) unsigned gwc_lds[];
+	announce_previous_call(a.announce, a.announce_seq);
+	if (blockIdx.x != 0) {
+		gram_wide_body<true>(a, gwc_lds, (int)blockIdx.x - 1, (int)gridDim.x - 1);
+		return;
+	}
+	if (threadIdx.x >= 256) return;
+	chol_wide4_body(cw, reinterpret_cast<double*>(gwc_lds));
 }
 
 }  // namespace tsqrmi
