@@ -123,7 +123,8 @@ int tsqr_mi_qr_f32_finish(tsqr_mi_ticket* ticket);
  *   depth 3  (default) depth 2, and for full 64-column matrices of 128 k <= 2^20 rows (16-byte aligned, no reorth) the chained
  *            schedule: the R-factor chain of call i (reduction of the Gram partials, Cholesky, verdict -- one workgroup busy, the
  *            rest of the chip idle) runs INSIDE the launch that is the Gram pass of call i + 1, so a call costs its two streaming
- *            passes and nothing else.  Needs count >= 3; wr holds two sets of Gram partials for it.
+ *            passes and nothing else.  Needs count >= 3; wr holds two sets of Gram partials for it.  Likewise for 128 columns (m a
+ *            multiple of 64, at least 510 blocks): the two-block factorisation of call i rides in the Gram launch of call i + 1.
  * At every depth every call runs all of its kernels, every verdict is read, a rejected matrix gets its whole ladder, and Q and R
  * are bit for bit those of the blocking call (tests/test_gpu_async.py).  Returns the first non-zero state. */
 int tsqr_mi_qr_f32_loop(int count, int mode, int reorth,
