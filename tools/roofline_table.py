@@ -9,7 +9,7 @@ WORK = [  # (timeline file, label, m, n)
     ("r03_timeline_c2_two_in_flight.txt", "2^20 x 64 fp32_tc_cor (stream of calls, two in flight)", 1 << 20, 64),
     ("r03_timeline_c2_blocking.txt", "2^20 x 64 fp32_tc_cor (blocking calls)", 1 << 20, 64),
     ("r03_timeline_c2_notc.txt", "2^20 x 64 fp32_notc", 1 << 20, 64),
-    ("r03_timeline_c3.txt", "2^20 x 128 fp32_tc_cor (one panel; stream of calls, two in flight)", 1 << 20, 128),
+    ("r03_timeline_c3.txt", "2^20 x 128 fp32_tc_cor (one panel; stream of calls, chained schedule)", 1 << 20, 128),
     ("r03_timeline_c3_blocking.txt", "2^20 x 128 fp32_tc_cor (one panel; blocking calls)", 1 << 20, 128),
     ("r03_timeline_c3_notc.txt", "2^20 x 128 fp32_notc (one panel)", 1 << 20, 128),
     ("r03_timeline_reorth.txt", "2^20 x 64 fp32_tc_cor, reorth", 1 << 20, 64),
@@ -19,7 +19,7 @@ WORK = [  # (timeline file, label, m, n)
 ]
 def algorithmic(kernel, m, n):
     """(bytes, flops) of one launch, or (None, None) for the n^3-scale one-workgroup kernels"""
-    if kernel.startswith(("gram_blk", "gram_bf16", "gram_wide", "gram_kernel", "fold_kernel")):
+    if kernel.startswith(("gram_blk", "gram_bf16", "gram_wide", "gram_kernel", "fold_kernel")):      # (incl. the chained launches gram_*_chain_kernel)
         return 4.0 * m * n, 2.0 * m * n * n / 2 if not kernel.startswith("fold_kernel") else 2.0 * m * n * n
     if kernel.startswith(("apply_wg", "apply_wide")):
         return 8.0 * m * n, 2.0 * m * n * n / (2 if "f32" not in kernel and n == 128 else 1) if n == 128 else 2.0 * m * n * n
