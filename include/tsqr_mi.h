@@ -155,7 +155,8 @@ int tsqr_mi_qr_f16(int mode, int reorth,
                    void* wq, void* wr, void* reorth_w, unsigned* d_wl, unsigned* h_wl,
                    void* stream);
 /* `count` calls (the reference's speed loop, src/test.cu:299-309) as tsqr_mi_qr_f32_loop: calls the native path takes (16 < n <= 64, no reorth,
- * aligned halves) are issued as a stream, two in flight (loop depth >= 2), everything else as blocking calls; the same halves either way */
+ * aligned halves) are issued as a stream -- two in flight (loop depth >= 2), for n = 64 and count >= 3 also the chained schedule (depth 3) --,
+ * everything else as blocking calls; the same halves either way */
 int tsqr_mi_qr_f16_loop(int count, int mode, int reorth,
                         void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
                         size_t m, size_t n,

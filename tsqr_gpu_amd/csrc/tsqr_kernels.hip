@@ -834,15 +834,14 @@ __global__ __launch_bounds__(256) void gram_bf16_kernel(const GramArgs a) {
 // the bytes of the fp32 pass.  One MFMA chain per 64-row chunk (64 accumulations per entry: far inside the chain lengths validated
 // for the bf16-split pass), fp64 totals; the next chunk's operands are requested before the current chunk's MFMAs.  Partials in the
 // format of gram_bf16_kernel.  The host sends lda % 8 == 0 and a 16-byte aligned base only (tsqr_mi_qr_f16 otherwise converts).
+// (the body takes its workgroup number as an argument: gram_h_chain_kernel runs it on a part of its grid; red: [2][NTRI * 256] doubles of LDS)
 template <int NT>
-__global__ __launch_bounds__(256) void gram_h_kernel(const GramArgs a) {
+__device__ __forceinline__ void gram_h_body(const GramArgs& a, double (*red)[((NT * (NT + 1)) / 2) * 256], const int wg) {
 	constexpr int NTRI = (NT * (NT + 1)) / 2;
-	__shared__ double red[2][NTRI * 256];
-	announce_previous_call(a.announce, a.announce_seq);
 	if (a.skip_status && a.skip_status[0] != 0) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
-	const int gw = blockIdx.x * 4 + wv;
+	const int gw = wg * 4 + wv;
 	const int c = lane & 15, q = lane >> 4;
 	const _Float16* A = reinterpret_cast<const _Float16*>(a.a);
 	f32x4 acc[NTRI];
@@ -922,12 +921,19 @@ __global__ __launch_bounds__(256) void gram_h_kernel(const GramArgs a) {
 	}
 	__syncthreads();
 	if (wv == 0) {
-		double* out = a.part + (size_t)blockIdx.x * NTRI * 256;
+		double* out = a.part + (size_t)wg * NTRI * 256;
 #pragma unroll
 		for (int t = 0; t < NTRI; t++)
 #pragma unroll
 			for (int r = 0; r < 4; r++) part_store(&out[(t * 4 + r) * 64 + lane], tot[t][r] + red[0][(t * 4 + r) * 64 + lane]);
 	}
+}
+template <int NT>
+__global__ __launch_bounds__(256) void gram_h_kernel(const GramArgs a) {
+	constexpr int NTRI = (NT * (NT + 1)) / 2;
+	__shared__ double red[2][NTRI * 256];
+	announce_previous_call(a.announce, a.announce_seq);
+	gram_h_body<NT>(a, red, blockIdx.x);
 }
 
 // gram_blk_kernel (round 3): the same Gram tiles for FULL 64-column matrices, with the block pattern of the apply pass on the load
@@ -1680,6 +1686,33 @@ __global__ __launch_bounds__(256, 2) void gram_blk_chain_kernel(const GramArgs a
 	const double* g = c.gsum;                            // (written by other workgroups of this launch: device-scope loads)
 	chol_body4(c.r, c.ldr, c.z, c.status, c.host_status, [&](int e) { return __hip_atomic_load(&g[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, c.n, c.NT, /*f32_layout=*/1, 0.03125f, max_scond, 0.0,
 	           rows * 0x1p-90, reinterpret_cast<double*>(gb_as));
+}
+
+// The same launch for a stream of fp16 calls (tsqr_mi_qr_f16_loop, n = 64): the R-factor chain of call i beside gram_h_kernel's body for
+// call i + 1.  One LDS array serves the three roles (reduction scratch, the Gram role's workgroup sum, chol_body4).
+__global__ __launch_bounds__(256) void gram_h_chain_kernel(const GramArgs a, const ChainArgs ch) {
+	__shared__ double hc_lds[64 * 65 + 4 * 256 + 128];
+	static_assert(sizeof(hc_lds) >= sizeof(double) * 2 * 10 * 256, "the Gram role's workgroup sum fits");
+	announce_previous_call(a.announce, a.announce_seq);
+	if ((int)blockIdx.x >= ch.nred) {
+		gram_h_body<4>(a, reinterpret_cast<double (*)[10 * 256]>(hc_lds), (int)blockIdx.x - ch.nred);
+		return;
+	}
+	const CholArgs& c = ch.chol;
+	gram_reduce1_body<true>(blockIdx.x, reinterpret_cast<double (*)[17]>(hc_lds), const_cast<double*>(c.gsum), ch.part, ch.nparts, 10 * 256, c.rows,
+	                        nullptr, 0, nullptr, 0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (write-through sums acknowledged, then the ticket: gram_blk_chain_kernel)
+	__syncthreads();
+	__shared__ unsigned last;
+	if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(ch.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ch.nred - 1)) ? 1u : 0u;
+	__syncthreads();
+	if (!last) return;
+	if (threadIdx.x == 0) __hip_atomic_store(ch.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const double rows = c.rows;
+	const float max_scond = fminf(128.0f, fmaxf(c.scond_floor, 0.12f * sqrtf((float)rows)));
+	const double* g = c.gsum;
+	chol_body4(c.r, c.ldr, c.z, c.status, c.host_status, [&](int e) { return __hip_atomic_load(&g[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, c.n, c.NT,
+	           /*f32_layout=*/1, 0.03125f, max_scond, 0.0, rows * 0x1p-90, hc_lds);
 }
 
 // ---------------------------------------------------------------------------------------------

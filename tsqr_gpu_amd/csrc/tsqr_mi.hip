@@ -1805,10 +1805,55 @@ static int stream_of_calls_f16(int count, int mode, void* q, size_t ldq, void* r
 	const int engine = engine_of(emode);
 	volatile unsigned* words = reinterpret_cast<volatile unsigned*>(c.hsig.host);
 	unsigned seq[2] = {0, 0};
+	// n = 64, three calls or more: the chained schedule (tsqr_mi_qr_f32_loop's, with gram_h_chain_kernel) -- the R-factor chain of call i
+	// inside the Gram launch of call i + 1, two sets of partials
+	const bool chained = (n == PW && count >= 3 && g_set.loop_depth.load() >= 3);
+	const GramPlan g = gram_plan(m, n);
+	const int nelem = 10 * 256, nred = nelem / 16;
+	double* part[2] = {reinterpret_cast<double*>(c.wr), reinterpret_cast<double*>(c.wr) + (size_t)g.nblocks * nelem};
+	unsigned* ticket = c.status_dev(0) + 8;
+	if (chained) HIPCHK(hipMemsetAsync(ticket, 0, sizeof(unsigned), c.st));
+	auto gram_h_args = [&](int i) {
+		tsqrmi::GramArgs ga{};
+		ga.a = reinterpret_cast<const float*>(a); ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = g.nch; ga.cpw = g.cpw; ga.nwaves = g.nwaves;
+		ga.part = part[i & 1];
+		ga.announce = c.announce_word; ga.announce_seq = c.announce_seq; c.announce_word = nullptr;
+		return ga;
+	};
+	auto chol_h_args = [&](int i) {
+		tsqrmi::CholArgs ca{};
+		ca.r = r32; ca.ldr = n; ca.z = c.wq + c.L.z;
+		ca.status = c.status_dev(i & 1);
+		ca.host_status = c.hsig.dev + 4 * (i & 1);
+		ca.gsum = c.gsum();
+		ca.rows = c.rows_global;
+		ca.n = (int)n; ca.NT = 4; ca.level = 2; ca.scond_floor = g_set.bf16_scond_floor;
+		return ca;
+	};
+	if (chained) {
+		hipLaunchKernelGGL(tsqrmi::gram_h_kernel<4>, dim3(g.nblocks), dim3(256), 0, c.st, gram_h_args(0));
+		HIPCHK(hipGetLastError());
+	}
 	auto step = [&](int i) -> int {                      // every launch of call i; c.announce_word (call i - 1's completion word) rides in its Gram kernel
 		c.slot = i & 1; c.prev_slot = -1;
-		int rc = gram_g(c, reinterpret_cast<const float*>(a), lda, m, n, /*bf16=*/true, /*io_half=*/true);
-		if (!rc) rc = chol_from_g(c, r32, n, n, 2);
+		int rc = 0;
+		if (chained) {
+			if (i + 1 < count) {
+				tsqrmi::ChainArgs ch{};
+				ch.chol = chol_h_args(i);
+				ch.part = part[i & 1]; ch.nparts = g.nblocks; ch.ticket = ticket; ch.nred = nred;
+				hipLaunchKernelGGL(tsqrmi::gram_h_chain_kernel, dim3(nred + g.nblocks), dim3(256), 0, c.st, gram_h_args(i + 1), ch);
+			} else {
+				if (c.announce_word) { hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, c.announce_word, c.announce_seq); c.announce_word = nullptr; }
+				hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nred), dim3(256), 0, c.st, c.gsum(), part[i & 1], g.nblocks, nelem, (double)m,
+				                   nullptr, (size_t)0, nullptr, 0);
+				hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, chol_h_args(i));
+			}
+			HIPCHK(hipGetLastError());
+		} else {
+			rc = gram_g(c, reinterpret_cast<const float*>(a), lda, m, n, /*bf16=*/true, /*io_half=*/true);
+			if (!rc) rc = chol_from_g(c, r32, n, n, 2);
+		}
 		if (!rc) rc = apply_rinv(c, engine, reinterpret_cast<float*>(q), ldq, reinterpret_cast<const float*>(a), lda, r32, n, m, n, /*z_ready=*/true,
 		                         c.status_dev(c.slot), /*io_half=*/true, r, ldr);
 		if (rc) return rc;
