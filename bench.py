@@ -8,9 +8,18 @@ M = 2^20 x N = 64 per GPU, fp32_tc_cor).
 A bare `python bench.py --gpus N` (N > 1, no launcher in front: WORLD_SIZE unset) starts its own N ranks: before anything touches
 the GPU it runs the torch.distributed.run command above as a child process, forwards its output and exits with its status.
 
-A "step" is one blocking mtk::qr::qr call (C ABI tsqr_mi_qr_f32, or the row-partitioned driver for N > 1) on a
-synthetic matrix already resident in HBM.  Weak scaling: every rank owns 2^20 rows (N = 8 is BASELINE's C4,
-2^23 x 64).  For n <= 64 the engine does not modify A, so no restore is needed between steps.
+A "step" is one factorisation (mtk::qr::qr; C ABI tsqr_mi_qr_f32, or the row-partitioned driver for N > 1) of a synthetic matrix
+already resident in HBM.  `value` / `ms_per_step` are the REFERENCE'S PROTOCOL: K BLOCKING calls one after the other on the same
+(q, r, a) -- src/test.cu:289-309 -- issued by one C loop (tsqr_mi_qr_f32_loop at loop depth 1: no interpreter time between calls),
+W untimed calls in front.  Beside it, each with its own roofline object (apply-pass duration from HIP events over a leg of the same
+schedule):
+  first_window     the same blocking window taken at process start (inside the GPU's clock / power transient after idle)
+  stream_same_a    the K calls as a stream on the same A (tsqr_mi_qr_f32_loop, depth 3: chained schedule where it applies)
+  stream_rotating  K calls over R >= 3 rotating (A, Q, R) triples through the batch entry (tsqr_mi_qr_f32_batch): no call finds its A
+                   in the 256 MiB Infinity Cache left there by an earlier call -- the cache-cold number
+  blocking_rotating  the same rotation as blocking calls
+Weak scaling (default): every rank owns 2^20 rows (N = 8 is BASELINE's C4, 2^23 x 64).  --scaling strong: the GLOBAL matrix is fixed
+(2^23 x 64 unless --m says otherwise) and split over the ranks.
 --workload selects the BASELINE.json configuration: c2 (default, the headline: 2^20 x 64 fp32_tc_cor U(-1,1)), c3 (2^20 x 128,
 --mode fp32_tc_cor | fp32_notc), c5 (latms cond 1e8, 2^20 x 64, Reorthogonalize = true); c4 is `--gpus 8` of c2's per-GPU shape.
 Prints ONE JSON line on rank 0 (contract in the task prompt) including `roofline` and `cpu_baseline` objects.
@@ -168,8 +177,17 @@ def parse_args(argv=None):
                     help="NO GPU: the per-rank executor is the numpy test double of tests/dist_double.py.  Exercises the launcher, the "
                          "collectives and the JSON plumbing on CPU; the numbers say nothing about the product and are labelled so")
     ap.add_argument("--ld-pad", type=int, default=0, help="leading dimension = m + pad (experiments on DRAM channel mapping)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --m rows PER GPU (default 2^20; N = 8 is BASELINE's C4).  strong: --m is the GLOBAL row count (default 2^23, "
+                         "SURVEY.md 8e) and every rank owns m / N rows")
+    ap.add_argument("--rotate", type=int, default=4, help="(A, Q, R) triples of the rotating-buffer windows (>= 3; 0 switches those windows off)")
+    ap.add_argument("--only-value", action="store_true", help="skip the extra windows (profiling runs): checked step, roofline leg, `value` window")
     args = ap.parse_args(argv)
     w = WORKLOADS[args.workload]
+    if args.scaling == "strong":
+        m_glob = args.m if args.m is not None else 1 << 23
+        assert m_glob % args.gpus == 0, "--scaling strong: the global row count must divide by --gpus"
+        args.m = m_glob // args.gpus
     for k in ("m", "n", "mode", "reorth"):
         if getattr(args, k) is None:
             setattr(args, k, w[k])
@@ -199,6 +217,30 @@ def make_input(args, m, n, m_glob, rank, dev):
     # C5: latms-style A = U diag(s) V^T with the reference's singular-value draw (src/test_cond.cu:31-50), cond 1e8, fixed seed
     from tsqr_gpu_amd import harness
     return harness.get_rand_matrix_with_cond_number(m, n, 1e8, seed=5, device=dev)
+
+
+def roofline_of(prof, steps, m, n, io_half, world):
+    """roofline object of the dominant kernel class of a profiled leg (HIP events on the engine's stream)"""
+    if not prof or not any(v[1] for v in prof.values()):
+        return None
+    dom = max(prof, key=lambda k: prof[k][0])
+    dom_ms, dom_launches = prof[dom]
+    per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
+    esz = 2.0 if io_half else 4.0                            # bytes per element of A and Q
+    if dom == "apply":                                       # Q = A * inverse(R): read A, write Q
+        bound, alg_bytes, alg_flops = "hbm", 2 * esz * m * n, 2.0 * m * n * n
+    elif dom == "gram":                                      # G = A^T A: read A once
+        bound, alg_bytes, alg_flops = "hbm", esz * m * n, 2.0 * m * n * n
+    else:                                                    # Householder fold: R factor of the local block
+        bound, alg_bytes, alg_flops = "mfma", 4.0 * m * n, f_r(m, n)
+    if bound == "hbm":
+        ach, peak, unit = alg_bytes / per_launch_s / 1e9, PEAK_HBM_TBS * 1e3, "GB/s"
+    else:
+        ach, peak, unit = alg_flops / per_launch_s / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
+    return {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+            "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
+            "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]}}
 
 
 def main():
@@ -247,14 +289,18 @@ def main():
     io_half = (not args.rehearse) and mode in bq.FP16_MODES   # the half-typed modes: fp16 in, fp16 out (one-GPU workloads)
     assert not io_half or (world == 1 and not args.force_dist), "the fp16 I/O modes are single-GPU entry points"
     io_dt = torch.float16 if io_half else torch.float32
-    d_a = make_input(args, m, n, m_glob, rank, dev).to(io_dt)
-    d_q = torch.empty(n, ld, dtype=io_dt, device=dev)[:, :m]
-    if args.ld_pad:
-        a_pad = torch.zeros(n, ld, dtype=io_dt, device=dev)
-        a_pad[:, :m] = d_a
-        d_a = a_pad[:, :m]
+    single = world == 1 and not args.force_dist and not args.rehearse
+
+    def new_triple(seed):
+        a = (make_input(args, m, n, m_glob, rank, dev) if seed == 0 else synth_block(m, n, m_glob, rank * m, seed, dev)).to(io_dt)
+        if args.ld_pad:
+            a_pad = torch.zeros(n, ld, dtype=io_dt, device=dev)
+            a_pad[:, :m] = a
+            a = a_pad[:, :m]
+        return a, torch.empty(n, ld, dtype=io_dt, device=dev)[:, :m], torch.zeros(n, n, dtype=io_dt, device=dev)
+
+    d_a, d_q, d_r = new_triple(0)
     a_keep = d_a.clone() if n > 64 else None                 # n > 64: the engine may overwrite A (it does not on the one-panel path)
-    d_r = torch.zeros(n, n, dtype=io_dt, device=dev)
     eng = None
     if args.rehearse:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -265,25 +311,39 @@ def main():
         def run_steps(k):
             for _ in range(k):
                 assert eng.qr(d_q, ld, d_r, d_a, ld, reorthogonalize=bool(args.reorth)) == 0
-    elif world == 1 and not args.force_dist:
+    elif single:
         bf = bq.buffer(mode, bool(args.reorth), device=dev)
         bf.allocate(m, n)
         loop = bq.bind_loop(d_q, ld, d_r, n, d_a, ld, m, n, bf)  # K calls issued by ONE C loop (tsqr_mi_qr_f32_loop): what a C++ caller's
         # loop costs (the reference's speed protocol is such a loop, src/test.cu:299-309), no interpreter time between calls.  The loop
-        # keeps the stream fed: call i + 1 is submitted before call i is finished (tsqr_mi_qr_f32_submit / _finish); every call runs
-        # all of its kernels and has its verdict looked at.  The same K calls as plain blocking calls are timed below as well.
+        # depth (bq.set_loop_depth) selects the protocol: 1 = blocking calls, 3 = a stream of calls (chained schedule where it applies).
 
         def run_steps(k):
             st = loop(k)
             assert st == 0, st
     else:
         from tsqr_gpu_amd import dist as tdist
-        eng = tdist.RowPartitionedQR(mode, m, n, comm=args.dist_comm)    # K steps = one C loop (two calls in flight); RCCL called from C on this stream
+        eng = tdist.RowPartitionedQR(mode, m, n, comm=args.dist_comm)    # K steps = one C loop; RCCL called from C on this stream
         dloop = eng.bind_loop(d_q, ld, d_r, d_a, ld, reorthogonalize=bool(args.reorth))
 
         def run_steps(k):
             st = dloop(k)
             assert st == 0, st                              # (complete on return, like the single-GPU loop)
+
+    # rotating buffers (one GPU, fp32 I/O): R triples more than an Infinity Cache apart, K calls = one call of the batch entry over the
+    # cyclic sequence of triples -- every call runs on an A the cache has not seen since R - 1 other matrices went through it
+    rot = None
+    if single and not io_half and args.rotate >= 3 and not args.only_value:
+        triples = [(d_a, d_q, d_r)] + [new_triple(s) for s in range(1, args.rotate)]
+        binds = {}
+
+        def run_rot(k):
+            if k not in binds:
+                seq = [triples[i % len(triples)] for i in range(k)]
+                binds[k] = bq.bind_batch([t[1] for t in seq], ld, [t[2] for t in seq], n, [t[0] for t in seq], ld, m, n, bf)
+            st, _ = binds[k]()
+            assert st == 0, st
+        rot = run_rot
 
     def barrier():
         if world > 1:
@@ -291,123 +351,149 @@ def main():
         if gpu:
             torch.cuda.synchronize()
 
-    def timed_window():
+    def set_depth(d):
+        if gpu:
+            bq.set_loop_depth(d)                            # (every rank alike: the loop depth is a per-process setting)
+
+    def timed_window(steps_fn, depth):
         """The contract's measurement: W untimed warm-up steps, then exactly K steps between barrier + synchronize, MAX over ranks."""
-        run_steps(args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        barrier()
-        dt = time.perf_counter() - t0
+        set_depth(depth)
+        try:
+            steps_fn(args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            steps_fn(args.steps)
+            barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            set_depth(3)
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt / args.steps * 1e3
 
-    # 1. one step, checked: accuracy of the factorisation evaluated in fp64 (global Q: all-reduce of Q_p^T Q_p), A untouched
+    def profiled_leg(steps_fn, depth):
+        """K steps of the same schedule under HIP events on the engine's stream: per-kernel-class durations (the roofline leg)"""
+        if not gpu:
+            return None
+        set_depth(depth)
+        bq.profile_enable(True)
+        try:
+            steps_fn(args.steps)
+            barrier()
+            return bq.profile_read()
+        finally:
+            bq.profile_enable(False)
+            set_depth(3)
+
+    def accuracy(q_t, r_t, a_t):
+        """||Q^T Q - I||_F and ||A - QR||_F / ||A||_F in fp64 (global Q: all-reduce of Q_p^T Q_p)"""
+        q64 = q_t.double()
+        gram = q64 @ q64.T
+        r64 = r_t.double().T.contiguous()
+        a64 = a_t.double()
+        res_num = ((r64.T @ q64) - a64).pow(2).sum().reshape(1)
+        res_den = a64.pow(2).sum().reshape(1)
+        if world > 1:
+            dist.all_reduce(gram); dist.all_reduce(res_num); dist.all_reduce(res_den)
+        return (float((gram - torch.eye(n, device=dev, dtype=torch.float64)).norm().item()), float(torch.sqrt(res_num / res_den).item()))
+
+    flops = f_qr(m_glob, n)
+
+    def window_obj(ms, prof, note):
+        o = {"ms_per_step": ms, "value": flops / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "note": note}
+        rf = roofline_of(prof, args.steps, m, n, io_half, world)
+        if rf is not None:
+            o["roofline"] = rf
+        return o
+
+    # 1. one blocking step, checked: accuracy of the factorisation evaluated in fp64, A untouched
+    set_depth(1)
     run_steps(1)
+    set_depth(3)
     barrier()
-    q64 = d_q.double()
-    gram = q64 @ q64.T
-    r64 = d_r.double().T.contiguous()
-    a64 = (a_keep if a_keep is not None else d_a).double()
-    res_num = ((r64.T @ q64) - a64).pow(2).sum().reshape(1)
-    res_den = a64.pow(2).sum().reshape(1)
-    if world > 1:
-        dist.all_reduce(gram); dist.all_reduce(res_num); dist.all_reduce(res_den)
-    orth_fro = float((gram - torch.eye(n, device=dev, dtype=torch.float64)).norm().item())
-    residual = float(torch.sqrt(res_num / res_den).item())
+    orth_first, res_first = accuracy(d_q, d_r, a_keep if a_keep is not None else d_a)
     a_untouched = True if a_keep is None else bool(torch.equal(a_keep, d_a))
     if not a_untouched:                                      # panel path for n > 64 (ill-conditioned input): every step needs a fresh A
         raise SystemExit("bench.py: the engine overwrote A on this workload; timing repeated calls on it would not measure the workload")
-    del q64, a64
 
-    # 2. a timing window at process start (reported as `first_window`, not as `value`): the first ~30 calls of a process run
-    #    5-8 % slower than all later ones (GPU clock / power settling after idle: tools/ramp.py, profiles/r02_experiment_log.md)
-    first_ms = None if (args.no_first_window or args.rehearse) else timed_window()
+    extras = {}
+    if not args.only_value and not args.rehearse:
+        # 2. the blocking window at process start: the first ~30 calls of a process run 5-8 % slower than all later ones (GPU clock /
+        #    power settling after idle: profiles/r02_experiment_log.md) -- the position round 2's `value` was taken at
+        if not args.no_first_window:
+            ms = timed_window(run_steps, 1)
+            extras["first_window"] = window_obj(ms, None, "the blocking-call window (as `value`) taken at process start, inside the GPU's clock / power transient after idle")
+        # 3. the K calls as a stream on the same A (loop entry, depth 3), and its own profiled leg
+        ms = timed_window(run_steps, 3)
+        extras["stream_same_a"] = window_obj(ms, profiled_leg(run_steps, 3),
+                                             "K calls of one C loop (tsqr_mi_qr_f32_loop / _dist_*_loop) issued as a stream: call i + 1 submitted before call i is finished; "
+                                             "full 64-column blocks of <= 2^20 rows: the R-factor chain of call i inside the Gram launch of call i + 1 (chained schedule).  "
+                                             "Same A every call (the reference's speed protocol): a 256 MiB A is largely Infinity-Cache resident between passes AND calls")
+        if rot is not None:
+            # 4. rotating triples: the batch entry (chained where the library takes it), then the same rotation as blocking calls
+            ms = timed_window(rot, 3)
+            extras["stream_rotating"] = window_obj(ms, profiled_leg(rot, 3),
+                                                   "K calls over %d rotating (A, Q, R) triples (%.0f MiB each) through tsqr_mi_qr_f32_batch, loop depth 3: no call finds its A in the "
+                                                   "256 MiB Infinity Cache from an earlier CALL (cache-cold across calls)" % (args.rotate, (2.0 * m * ld + n * n) * 4 / 2 ** 20))
+            ms = timed_window(rot, 2)
+            extras["two_in_flight_rotating"] = window_obj(ms, None, "the same rotation, two calls in flight in stream order (tsqr_mi_qr_f32_batch at loop depth 2)")
+            ms = timed_window(rot, 1)
+            extras["blocking_rotating"] = window_obj(ms, profiled_leg(rot, 1), "the same rotation as blocking calls (tsqr_mi_qr_f32_batch at loop depth 1)")
+            o2, r2 = accuracy(triples[-1][1], triples[-1][2], triples[-1][0])
+            extras["stream_rotating"]["orth_fro_last_triple"] = o2
+            extras["stream_rotating"]["residual_last_triple"] = r2
 
-    # 3. per-kernel-class timing with HIP events on the engine's stream, K steps (the roofline leg)
-    prof = None
-    if gpu:
-        bq.profile_enable(True)
-        run_steps(args.steps)
-        barrier()
-        prof = bq.profile_read()
-        bq.profile_enable(False)
-
-    # 4. the same window as 5. with the loop entry degraded to plain blocking calls (one host round trip per call): reported, not `value`
-    blocking_ms = None
-    if gpu and not args.rehearse:                             # (every rank alike: the loop depth is a per-process setting)
-        bq.set_loop_depth(1)
-        try:
-            blocking_ms = timed_window()
-        finally:
-            bq.set_loop_depth(3)
-    # 5. the contract's window
-    ms_per_step = timed_window()
-    flops = f_qr(m_glob, n)
+    # 5. the roofline leg of `value`: K blocking calls under HIP events
+    prof = profiled_leg(run_steps, 1)
+    # 6. the contract's window: W + K BLOCKING calls (the reference's protocol, src/test.cu:289-309)
+    ms_per_step = timed_window(run_steps, 1)
     gflops = flops / (ms_per_step * 1e-3) / 1e9
+    # accuracy of what the timed schedule left in Q and R (the last call of the window)
+    orth_fro, residual = accuracy(d_q, d_r, a_keep if a_keep is not None else d_a)
 
     if rank == 0:
         engine_name = "numpy-double (rehearsal)" if args.rehearse else bq.ENGINE_NAMES.get(eng.last_engine if eng is not None else bq.last_engine(), "?")
-        roofline = None
-        if prof is not None:
-            dom = max(prof, key=lambda k: prof[k][0])
-            dom_ms, dom_launches = prof[dom]
-            per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
-            # algorithmic work of one launch of the dominant kernel (DESIGN.md section 4)
-            esz = 2.0 if io_half else 4.0                       # bytes per element of A and Q
-            if dom == "apply":                                  # Q = A * inverse(R): read A, write Q
-                bound, alg_bytes, alg_flops = "hbm", 2 * esz * m * n, 2.0 * m * n * n
-            elif dom == "gram":                                 # G = A^T A: read A once
-                bound, alg_bytes, alg_flops = "hbm", esz * m * n, 2.0 * m * n * n
-            else:                                               # Householder fold: R factor of the local block
-                bound, alg_bytes, alg_flops = "mfma", 4.0 * m * n, f_r(m, n)
-            if bound == "hbm":
-                ach, peak, unit = alg_bytes / per_launch_s / 1e9, PEAK_HBM_TBS * 1e3, "GB/s"
-            else:
-                ach, peak, unit = alg_flops / per_launch_s / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
-            traffic, traffic_source = pmc_traffic(dom, m, n, args.mode) if args.workload == "c2" else (None, None)
-            roofline = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                        "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
-                        "note": "HBM fractions are fabric-side: the same A is factored every step (the reference's own protocol, "
-                                "src/test.cu:299-309) and a 256 MiB A stays largely resident in the 256 MiB Infinity Cache between the two "
-                                "passes and between steps; FETCH_SIZE counts those hits as memory-side requests",
-                        "avg_launch_us": per_launch_s * 1e6, "launches": dom_launches,
-                        "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
-                        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
-                        "r_factor_engine": engine_name,
-                        "whole_path": {"tflops": gflops / 1e3 / world, "peak_tflops_f32_matrix": PEAK_F32_MATRIX_TFLOPS,
-                                       "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
-                                       "algorithmic_gbs": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e9,
-                                       "frac_hbm_peak": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e12 / PEAK_HBM_TBS}}
+        roofline = roofline_of(prof, args.steps, m, n, io_half, world)
+        if roofline is not None:
+            traffic, traffic_source = pmc_traffic(roofline["kernel"], m, n, args.mode) if args.workload == "c2" and args.scaling == "weak" else (None, None)
+            roofline.update({"traffic": traffic, "traffic_source": traffic_source,
+                             "note": "blocking calls on the SAME A (the reference's own protocol, src/test.cu:299-309): a 256 MiB A stays largely resident in the 256 MiB "
+                                     "Infinity Cache between the two passes and between steps, so this HBM fraction is fabric-side (FETCH_SIZE counts those hits as "
+                                     "memory-side requests); stream_rotating / blocking_rotating carry the cache-cold rooflines",
+                             "r_factor_engine": engine_name,
+                             "whole_path": {"tflops": gflops / 1e3 / world, "peak_tflops_f32_matrix": PEAK_F32_MATRIX_TFLOPS,
+                                            "frac_f32_matrix_peak": gflops / 1e3 / world / PEAK_F32_MATRIX_TFLOPS,
+                                            "algorithmic_gbs": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e9,
+                                            "frac_hbm_peak": 4.0 * (2 * m * n + n * n) / (ms_per_step * 1e-3) / 1e12 / PEAK_HBM_TBS}})
         inp = "U(-1,1)" if args.input == "uniform" else "latms cond 1e8 (src/test_cond.cu:31-50 spectrum, seed 5)"
+        exchange = None
+        if eng is not None:                                  # what the ranks exchange per call (DESIGN.md section 6)
+            exchange = ("r_allgather: all-gather of the n x n local R factors (%d B per rank), Householder engine" % (4 * min(n, 64) ** 2) if args.policy == 1 else
+                        "gram_allreduce: all-reduce of the Gram tiles + row count (%d doubles = %d B), Gram engines; the Householder engine's "
+                        "r_allgather only as the ladder's last resort" % (10 * 256 + 1, 8 * (10 * 256 + 1)))
         out = {"metric": "tsqr_gflops", "value": gflops, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+               "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": ("f16 in / out, f32 accumulation" if io_half else "f32"),
                "data": "synthetic",
-               "config": {"workload": "%s: M=2^%d x N=%d per GPU, %s, reorth=%d, %s; global %d x %d; F_QR=4MN^2-4/3N^3; R-factor engine: %s" % (
-                   args.workload, int(np.log2(m)) if m & (m - 1) == 0 else -1, n, args.mode, args.reorth, inp, m_glob, n, engine_name),
+               "config": {"workload": "%s: M=%s x N=%d per GPU, %s, reorth=%d, %s; global %d x %d (%s scaling); F_QR=4MN^2-4/3N^3; R-factor engine: %s" % (
+                   args.workload, ("2^%d" % int(np.log2(m))) if m & (m - 1) == 0 else str(m), n, args.mode, args.reorth, inp, m_glob, n, args.scaling, engine_name),
                    "engine": engine_name, "m_per_gpu": m, "n": n, "mode": args.mode, "reorthogonalize": bool(args.reorth),
                    "parallelism": "row-partitioned x%d" % world,
-                   "dist_transport": (eng.transport if eng is not None else None)},
+                   "dist_transport": (eng.transport if eng is not None else None), "dist_exchange": exchange},
+               "call_protocol": "value / ms_per_step: K BLOCKING calls on the same (q, r, a), one after the other (reference src/test.cu:289-309), issued by one C loop "
+                                "(loop depth 1), W untimed calls in front; taken in steady state (window_order) -- first_window is the same window at process start",
                "orth_fro": orth_fro, "orth_ref_metric": orth_fro / np.sqrt(n), "residual": residual,
-               "window_order": "1 checked step, first_window (W + K), K steps under HIP events, blocking_calls (W + K), then the W + K window `value` is taken from",
+               "orth_fro_checked_step": orth_first, "residual_checked_step": res_first,
+               "window_order": "1 checked blocking step; first_window (W + K blocking); stream_same_a (W + K, then K under HIP events); stream_rotating, "
+                               "two_in_flight_rotating, blocking_rotating (W + K each; K under events for the first and the last); K blocking calls under HIP events "
+                               "(`roofline`); then the W + K blocking window `value` is taken from; orth_fro / residual are evaluated on the Q and R that window left",
                "roofline": roofline}
+        out.update(extras)
         if args.rehearse:
             out["rehearsal"] = True
             out["data"] = "synthetic (CPU rehearsal with the numpy test double: NOT a measurement of the product)"
-        if blocking_ms is not None:
-            out["call_protocol"] = ("the K calls of the window are ONE call of the C loop entry (tsqr_mi_qr_f32_loop / _dist_*_loop), issued as a stream: call i + 1 "
-                                    "is submitted before call i is finished (two in flight); for full 64-column matrices of <= 2^20 rows on one GPU the "
-                                    "R-factor chain of call i (reduction, Cholesky, verdict) runs inside the Gram launch of call i + 1.  Every call runs "
-                                    "all of its kernels, every conditioning verdict is read, Q and R are bit for bit those of the blocking call; "
-                                    "`blocking_calls` is the same window with one blocking call after the other (tsqr_mi_set_loop_depth(1))")
-            out["blocking_calls"] = {"ms_per_step": blocking_ms, "value": flops / (blocking_ms * 1e-3) / 1e9, "unit": "GFLOP/s"}
-        if first_ms is not None:
-            out["first_window"] = {"ms_per_step": first_ms, "value": flops / (first_ms * 1e-3) / 1e9, "unit": "GFLOP/s",
-                                   "note": "the same W + K window taken at process start, inside the GPU's clock / power transient after idle"}
         if world == 1 and not args.no_cpu_baseline and not args.rehearse and not io_half:
             out["cpu_baseline"] = cpu_baseline(n, args.mode, args.cpu_sample_rows)
         print(json.dumps(out))

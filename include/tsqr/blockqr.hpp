@@ -45,6 +45,21 @@ const state_t error_unsupported_mode = 2;      // new: compute_mode without a gf
 
 using handle_t = hipStream_t;                  // takes the place of cublasHandle_t (see the header comment)
 
+// reference src/blockqr.hpp:31-43: the one-panel engine's name for a block-QR mode (same enumerator names in both enums)
+template <mtk::qr::compute_mode>
+constexpr mtk::tsqr::compute_mode get_tsqr_compute_mode();
+#define BQR_GET_TSQR_COMPUTE_MODE(mode) template<> constexpr mtk::tsqr::compute_mode get_tsqr_compute_mode<mtk::qr::compute_mode::mode>() {return mtk::tsqr::compute_mode::mode;}
+BQR_GET_TSQR_COMPUTE_MODE(fp16_notc        );
+BQR_GET_TSQR_COMPUTE_MODE(fp32_notc        );
+BQR_GET_TSQR_COMPUTE_MODE(fp16_tc_nocor    );
+BQR_GET_TSQR_COMPUTE_MODE(fp32_tc_nocor    );
+BQR_GET_TSQR_COMPUTE_MODE(tf32_tc_nocor    );
+BQR_GET_TSQR_COMPUTE_MODE(fp32_tc_cor      );
+BQR_GET_TSQR_COMPUTE_MODE(tf32_tc_cor      );
+BQR_GET_TSQR_COMPUTE_MODE(tf32_tc_cor_emu  );
+BQR_GET_TSQR_COMPUTE_MODE(tf32_tc_nocor_emu);
+BQR_GET_TSQR_COMPUTE_MODE(mixed_tc_cor_emu );
+
 // Element types, as in reference src/tsqr.hpp:25-39 for the io type: float for the fp32 modes, IEEE binary16 (the reference's
 // `half`) for fp16_notc / fp16_tc_nocor.  The WORKING types are float for every mode (the reference's are half for the fp16 modes
 // and for the working Q of fp32_tc_nocor): this engine factors in fp32 and converts at the boundary.  The remaining modes are
@@ -238,6 +253,29 @@ inline void qr_submit(
 inline state_t qr_finish(ticket& t) {
 	const int st = tsqr_mi_qr_f32_finish(&t);
 	if (st < 0) throw std::runtime_error(std::string("mtk::qr::qr_finish: ") + tsqr_mi_last_error());
+	return st;
+}
+
+// Not in the reference either: `count` different matrices of one shape through one call (tsqr_mi_qr_f32_batch).  What a caller's loop
+//     for (i = 0; i < count; i++) mtk::qr::qr<mode, Reorth>(q[i], ldq, r[i], ldr, a[i], lda, m, n, buffer, handle);
+// computes -- bit for bit, including the fallback ladder of a matrix the conditioning check rejects -- issued as a stream: the 22 us
+// in which one workgroup factors the Gram matrix of matrix i are hidden in the Gram pass of matrix i + 1 (tsqr_mi.h for the rules:
+// q[i] and r[i] must be clear of a[i + 1] for that; in place, q[i] == a[i], is fine).  q, r, a: host arrays of device pointers.
+// states (optional): the state_t of every call.  Returns the first non-zero state_t.  fp32 I/O modes.
+template <mtk::qr::compute_mode mode, bool Reorthogonalize>
+inline state_t qr_batch(
+		const std::size_t count,
+		float* const* const q_ptrs, const std::size_t ldq,
+		float* const* const r_ptrs, const std::size_t ldr,
+		float* const* const a_ptrs, const std::size_t lda,
+		const std::size_t m, const std::size_t n,
+		buffer<mode, Reorthogonalize>& bf,
+		handle_t const stream = nullptr,
+		state_t* const states = nullptr) {
+	static_assert(std::is_same<typename mtk::qr::get_io_type<mode>::type, float>::value, "qr_batch takes the fp32 I/O modes");
+	const int st = tsqr_mi_qr_f32_batch(static_cast<int>(count), static_cast<int>(mode), Reorthogonalize ? 1 : 0, q_ptrs, ldq, r_ptrs, ldr, a_ptrs, lda, m, n,
+	                                    bf.dwq, bf.dwr, bf.dw_reorth_r, bf.dl, bf.hl, stream, states);
+	if (st < 0) throw std::runtime_error(std::string("mtk::qr::qr_batch: ") + tsqr_mi_last_error());
 	return st;
 }
 }  // namespace qr

@@ -126,13 +126,33 @@ int tsqr_mi_qr_f32_finish(tsqr_mi_ticket* ticket);
  *            passes and nothing else.  Needs count >= 3; wr holds two sets of Gram partials for it.  Likewise for 128 columns (m a
  *            multiple of 64, at least 510 blocks): the two-block factorisation of call i rides in the Gram launch of call i + 1.
  * At every depth every call runs all of its kernels, every verdict is read, a rejected matrix gets its whole ladder, and Q and R
- * are bit for bit those of the blocking call (tests/test_gpu_async.py).  Returns the first non-zero state. */
+ * are bit for bit those of the blocking call (tests/test_gpu_async.py).  Returns the first non-zero state.
+ * The chained schedules launch the Gram pass of call i + 1 before the apply pass of call i; they are taken only when that is the
+ * blocking order, i.e. when Q and R do not overlap A (a loop that factors in place, q == a, runs at depth 2: call i + 1 of the
+ * blocking loop factors the Q that call i left in A, and so does the stream). */
 int tsqr_mi_qr_f32_loop(int count, int mode, int reorth,
                         float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                         size_t m, size_t n,
                         void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
                         void* stream);
-void tsqr_mi_set_loop_depth(int depth);   /* 1, 2 or 3 (default); applies to every *_loop entry of the process */
+void tsqr_mi_set_loop_depth(int depth);   /* 1, 2 or 3 (default); applies to every *_loop and *_batch entry of the process */
+
+/* `count` DIFFERENT matrices of one shape: the caller of mtk::qr::qr with many matrices to factor (the reference's README.md:52-87
+ * call inside the caller's loop over its matrices).  q, r, a are HOST arrays of `count` device pointers: call i factors a[i] (m x n,
+ * lda) into q[i] (ldq) and r[i] (ldr); the leading dimensions, the shape, the mode and the work buffers are shared.  The calls are
+ * issued as the stream tsqr_mi_qr_f32_loop issues (tsqr_mi_set_loop_depth): at depth 3 full 64-column matrices of 128 k <= 2^20 rows
+ * (and 128-column matrices of 64 k >= 32640 rows) take the chained schedule -- the R-factor chain of matrix i inside the Gram launch of
+ * matrix i + 1 -- as long as no output of call i is an input of call i + 1 (q[i], r[i] clear of a[i + 1]; q[i] == a[i], in place, is
+ * fine); everything else, and everything at depth 2, runs two calls in flight in stream order; depth 1 is a loop of blocking calls.
+ * Whatever the schedule, every matrix gets the blocking call's result bit for bit: a matrix the conditioning check rejects mid-batch
+ * gets its whole ladder (the chained schedule ends at it and a fresh one starts behind it), the accepted ones around it stand.
+ * states (optional, `count` ints): the state of every call.  Returns the first non-zero state (0: all factored); a negative value
+ * (runtime failure) ends the batch at once.  Blocking: complete on return. */
+int tsqr_mi_qr_f32_batch(int count, int mode, int reorth,
+                         float* const* q, size_t ldq, float* const* r, size_t ldr, float* const* a, size_t lda,
+                         size_t m, size_t n,
+                         void* wq, void* wr, float* reorth_w, unsigned* d_wl, unsigned* h_wl,
+                         void* stream, int* states);
 
 /*
  * The fp16 I/O modes: replaces mtk::qr::qr<fp16_notc | fp16_tc_nocor, Reorthogonalize> (reference src/blockqr.cu:437-449; io type
@@ -215,8 +235,9 @@ int tsqr_mi_rmul_f32(float* r, size_t ldr, const float* r2, size_t ldr2, size_t 
  *   torch.distributed over gloo -- what the multi-process tests use.
  * *_loop: `count` calls as a stream (see tsqr_mi_qr_f32_loop); every rank must pass the same count and run at the same loop depth -- the
  *   ranks take the same verdicts, hence the same path through the loop and the same order of collectives.  Depth 3, count >= 3: when
- *   EVERY rank holds a full 64-column block of 128 k <= 2^20 rows (agreed on by one all-reduce of flags per loop call) the Cholesky
- *   launch of call i rides in the Gram launch of call i + 1 and allreduce(i + 1) is enqueued before apply(i). */
+ *   EVERY rank holds a full 64-column block of 128 k <= 2^20 rows the Cholesky launch of call i rides in the Gram launch of call i + 1
+ *   and allreduce(i + 1) is enqueued before apply(i).  The ranks agree on that without a collective of its own: the first all-reduce
+ *   of the loop call (the Gram tiles of call 0) carries one more double, 1.0 from every eligible rank; nranks <= 255. */
 size_t tsqr_mi_working_q_size_dist(size_t m_local, size_t n, int nranks);
 size_t tsqr_mi_working_r_size_dist(size_t m_local, size_t n, int nranks);
 int tsqr_mi_qr_f32_dist(int mode, int reorth,

@@ -89,3 +89,4 @@ def test_cpp_header_compiles_and_links(bq):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
     assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "sample_blockqr"))
     assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "sample_tsqr16"))       # include/tsqr/tsqr.hpp: mtk::tsqr::tsqr16 / buffer
+    assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "sample_batch"))        # mtk::qr::qr_batch, get_tsqr_compute_mode<> (static_asserts)

@@ -55,6 +55,24 @@ def test_single_rank_rehearsal_and_workload_names():
     assert (a.workload, a.m, a.n, a.mode, a.reorth, a.gpus) == ("c2", 1 << 20, 64, "fp32_tc_cor", 0, 1)
 
 
+def test_world_size_8_rehearsal_weak_and_strong():
+    """the N = 8 launch (BASELINE's C4 shape of ranks) rehearsed on CPU -- eight gloo ranks, the numpy double as the
+    per-rank executor -- in both scaling modes.  weak: --m rows per rank; strong: --m is the GLOBAL row count, split over the ranks."""
+    d = _bench("--gpus", "8", "--backend", "gloo", "--rehearse", "--m", "1024", "--steps", "2", "--warmup", "1")
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["m_per_gpu"] == 1024 and "8192 x 64" in d["config"]["workload"]
+    assert d["config"]["parallelism"] == "row-partitioned x8" and d["config"]["dist_exchange"].startswith("gram_allreduce")
+    assert d["orth_fro"] < 1e-5 and d["residual"] < 1e-6
+    d = _bench("--gpus", "8", "--backend", "gloo", "--rehearse", "--scaling", "strong", "--m", "8192", "--steps", "2", "--warmup", "1")
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["m_per_gpu"] == 1024 and "8192 x 64" in d["config"]["workload"]
+    assert d["orth_fro"] < 1e-5 and d["residual"] < 1e-6
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--scaling", "strong", "--gpus", "4"])
+    assert a.m == (1 << 23) // 4                                 # default global matrix of the strong mode: 2^23 x 64 (SURVEY.md 8e)
+    a = bench.parse_args(["--scaling", "strong", "--gpus", "1"])
+    assert a.m == 1 << 23
+
+
 def test_launcher_failure_is_reported():
     """a rank that fails makes the bare invocation exit non-zero (the children's status is forwarded)"""
     env = dict(os.environ)

@@ -99,3 +99,48 @@ def test_two_rank_escalation_is_identical_on_all_ranks():
     assert res["rows_seen"] == [1200.0] * 4
     res = _run((600, 500), 32, False, reject=(2, 1))          # nothing Gram-based works -> Householder all-gather path
     assert res["st"] == 0 and res["r_same"] and res["engine"] == 2 and res["orth"] < 1e-5 and res["res"] < 1e-6
+
+
+def _worker_heights_change(rank, world, port, n, out):
+    """the empty-block check of a per-call m_local is collective.  Only rank 1's block shrinks on the second call; both
+    ranks pass m_local to that call (rank 0 its unchanged height) -- every rank posts the check's all-reduce, nothing hangs, and the
+    Gram all-reduce that follows pairs with the right collective."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tsqr_gpu_amd import dist as tdist
+    rng = np.random.Generator(np.random.MT19937(7 + rank))
+    m0 = 400
+    backend = NumpyRowBackend(n, tdist.TorchCollectives())
+    drv = tdist.RowPartitionedQR(3, m0, n, backend=backend)
+    a_full = rng.uniform(-1, 1, size=(m0, n)).astype(np.float32)
+    results = []
+    for m_local in ((m0, m0), (m0, 150), (m0, 0))[0:3]:
+        ml = m_local[rank]
+        a = torch.from_numpy(np.ascontiguousarray(a_full[:ml].T)) if ml else torch.zeros(n, 1)
+        q = torch.zeros(n, max(ml, 1)); r = torch.zeros(n, n)
+        try:
+            st = drv.qr(q, max(ml, 1), r, a, max(ml, 1), m_local=ml)
+            results.append(("ok", st, float(backend.rows_seen[-1])))
+        except ValueError:
+            results.append(("empty", None, None))              # raised on EVERY rank when any rank's block is empty
+    gathered = [None] * world
+    dist.all_gather_object(gathered, results)
+    if rank == 0:
+        out.put(gathered)
+    dist.destroy_process_group()
+
+
+def test_per_call_block_height_is_a_collective_decision():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_heights_change, args=(r, 2, port, 16, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]                                    # both ranks saw the same sequence of outcomes
+    assert res[0][0] == ("ok", 0, 800.0) and res[0][1] == ("ok", 0, 550.0) and res[0][2] == ("empty", None, None)

@@ -242,3 +242,173 @@ def test_chained_schedule_shapes(bq, oracle, torch_cuda, m, pad, count, mode):
     if mode != "fp32_tc_nocor":                                          # (uncorrected fp16 products: 1e-3 by construction)
         q = res[1][0].T.astype(np.float64)
         assert oracle.orthogonality_fro(q) < 5e-6 and oracle.residual(a, q, res[1][1].T.astype(np.float64)) < 5e-6
+
+
+# ---- the batch entry (tsqr_mi_qr_f32_batch): many DIFFERENT matrices through the stream the loop entry issues ----
+class Batch:
+    """K problems of one shape sharing one work buffer; q_of[i] / a_of[i] let a test alias outputs onto inputs"""
+
+    def __init__(self, bq, torch, mats, mode, inplace=False, ld_pad=0):
+        self.m, self.n = mats[0].shape
+        self.ld = self.m + ld_pad
+        self.mode = mode
+        self.bf = bq.buffer(mode, False)
+        self.bf.allocate(self.m, self.n)
+        self.hosts = []
+        self.d_a, self.d_q, self.d_r = [], [], []
+        for a in mats:
+            buf = np.zeros((self.n, self.ld), np.float32); buf[:, :self.m] = a.T
+            self.hosts.append(buf)
+            self.d_a.append(torch.from_numpy(buf.copy()).cuda())
+            self.d_q.append(self.d_a[-1] if inplace else torch.full((self.n, self.ld), float("nan"), dtype=torch.float32, device="cuda"))
+            self.d_r.append(torch.zeros(self.n, self.n, dtype=torch.float32, device="cuda"))
+
+    def run(self, bq):
+        return bq.qr_batch(self.d_q, self.ld, self.d_r, self.n, self.d_a, self.ld, self.m, self.n, self.bf)
+
+    def results(self):
+        return [(q.cpu().numpy()[:, :self.m].copy(), r.cpu().numpy().copy()) for q, r in zip(self.d_q, self.d_r)]
+
+
+def batch_at_depths(bq, torch, mats, mode, **kw):
+    """the batch at loop depth 1 (blocking calls), 2 (two in flight), 3 (chained where it applies): results per depth + states"""
+    out = []
+    for depth in (1, 2, 3):
+        bq.set_loop_depth(depth)
+        try:
+            b = Batch(bq, torch, mats, mode, **kw)
+            st, states = b.run(bq)
+            out.append((st, states, b.results(), b))
+        finally:
+            bq.set_loop_depth(3)
+    return out
+
+
+@pytest.mark.parametrize("mode", ["fp32_tc_cor", "fp32_notc"])
+@pytest.mark.parametrize("m,n,k,pad", [(1 << 16, 64, 5, 0), (4096, 64, 3, 4), (1 << 18, 64, 4, 0), (9211, 51, 4, 0), (64 * 520, 128, 4, 0), (20000, 100, 3, 0)])
+def test_batch_of_different_matrices_is_the_blocking_calls(bq, oracle, torch_cuda, m, n, k, pad, mode):
+    """K different matrices: every schedule returns, bit for bit, what K blocking calls return (chained for 128 k x 64 and 64 k x 128)."""
+    md = bq.compute_mode[mode]
+    mats = [oracle.uniform_matrix(m, n, seed=40 + i) for i in range(k)]
+    want = [blocking(bq, torch_cuda, a, md) for a in mats] if pad == 0 else None
+    res = batch_at_depths(bq, torch_cuda, mats, md, ld_pad=pad)
+    for st, states, rs, b in res:
+        assert st == 0 and states == [0] * k
+        for i in range(k):
+            assert np.array_equal(rs[i][0], res[0][2][i][0]) and np.array_equal(rs[i][1], res[0][2][i][1])
+            if want is not None:
+                assert same(rs[i], want[i])
+            assert np.array_equal(b.d_a[i].cpu().numpy(), b.hosts[i])        # A untouched (one panel / accepted one-panel path)
+    # different matrices really gave different factors
+    assert not np.array_equal(res[2][2][0][1], res[2][2][1][1])
+
+
+@pytest.mark.parametrize("bad", [[2], [0], [4], [1, 2], [0, 1, 2, 3, 4]])
+def test_batch_with_rejected_matrices(bq, oracle, torch_cuda, bad):
+    """Matrices the bf16-split level rejects anywhere in a chained batch: they get their whole ladder, the accepted ones around them
+    stand, the schedule goes on behind them -- every result is the blocking call's."""
+    md = bq.compute_mode.fp32_tc_cor
+    m, n, k = 1 << 15, 64, 5
+    mats = [oracle.matrix_with_cond(m, n, 1e6, seed=60 + i).astype(np.float32) if i in bad else oracle.uniform_matrix(m, n, seed=60 + i) for i in range(k)]
+    want = [blocking(bq, torch_cuda, a, md) for a in mats]
+    for i in range(k):
+        assert (want[i][1] != 3) == (i in bad)
+    for st, states, rs, b in batch_at_depths(bq, torch_cuda, mats, md):
+        assert st == 0 and states == [0] * k
+        for i in range(k):
+            assert same(rs[i], want[i]), (i, bad)
+
+
+def test_batch_in_place(bq, oracle, torch_cuda):
+    """q[i] == a[i]: allowed by the chained schedule (Q(i) is clear of A(i + 1)); an accepted call is never redone when a later
+    one is rejected."""
+    md = bq.compute_mode.fp32_tc_cor
+    m, n, k = 1 << 15, 64, 6
+    mats = [oracle.uniform_matrix(m, n, seed=80 + i) for i in range(k)]
+    mats[2] = oracle.matrix_with_cond(m, n, 1e6, seed=82).astype(np.float32)
+    want = [blocking(bq, torch_cuda, a, md) for a in mats]
+    for st, states, rs, b in batch_at_depths(bq, torch_cuda, mats, md, inplace=True):
+        assert st == 0 and states == [0] * k
+        for i in range(k):
+            assert same(rs[i], want[i]), i
+
+
+def test_batch_output_feeding_the_next_input(bq, oracle, torch_cuda):
+    """q[i] is a[i + 1]: call i + 1 must factor what call i wrote -- the blocking order.  The chained schedule would read A(i + 1)
+    before Q(i) is there; the library sees the overlap and runs the batch in stream order."""
+    torch = torch_cuda
+    md = bq.compute_mode.fp32_tc_cor
+    m, n, k = 1 << 14, 64, 4
+    a0 = oracle.uniform_matrix(m, n, seed=90)
+    res = []
+    for depth in (1, 3):
+        bufs = [torch.from_numpy(np.ascontiguousarray(a0.T)).cuda()] + [torch.zeros(n, m, dtype=torch.float32, device="cuda") for _ in range(k)]
+        rs = [torch.zeros(n, n, dtype=torch.float32, device="cuda") for _ in range(k)]
+        bf = bq.buffer(md, False); bf.allocate(m, n)
+        bq.set_loop_depth(depth)
+        try:
+            st, states = bq.qr_batch(bufs[1:], m, rs, n, bufs[:-1], m, m, n, bf)       # a[i] = bufs[i], q[i] = bufs[i + 1] = a[i + 1]
+        finally:
+            bq.set_loop_depth(3)
+        assert st == 0 and states == [0] * k
+        res.append(([b.cpu().numpy() for b in bufs], [r.cpu().numpy() for r in rs]))
+    for x, y in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert np.array_equal(x, y)
+    r1 = res[1][1][1].T                                                   # R of an orthonormal input: the identity up to signs
+    assert np.abs(np.abs(np.diag(r1)) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("m,n", [(1 << 16, 64), (64 * 520, 128)])
+def test_loop_entry_in_place_agrees_at_every_depth(bq, oracle, torch_cuda, m, n):
+    """tsqr_mi_qr_f32_loop with q == a.  Call i + 1 of the blocking loop factors the Q that call i left in A; the chained
+    schedule (Gram pass of call i + 1 before the apply pass of call i) must not be taken -- all depths give the blocking loop's result."""
+    torch = torch_cuda
+    md = bq.compute_mode.fp32_tc_cor
+    a = oracle.uniform_matrix(m, n, seed=95)
+    res = []
+    for depth in (1, 2, 3):
+        d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+        d_r = torch.zeros(n, n, dtype=torch.float32, device="cuda")
+        bf = bq.buffer(md, False); bf.allocate(m, n)
+        bq.set_loop_depth(depth)
+        try:
+            assert bq.bind_loop(d_a, m, d_r, n, d_a, m, m, n, bf)(4) == 0
+        finally:
+            bq.set_loop_depth(3)
+        res.append((d_a.cpu().numpy(), d_r.cpu().numpy()))
+    for k in (1, 2):
+        assert np.array_equal(res[0][0], res[k][0]) and np.array_equal(res[0][1], res[k][1])
+    q = res[2][0].T.astype(np.float64)
+    assert oracle.orthogonality_fro(q) < 5e-6
+    assert np.abs(np.abs(np.diag(res[2][1])) - 1).max() < 1e-5           # the last call factored an orthonormal matrix
+
+
+def test_batch_edge_cases(bq, oracle, torch_cuda):
+    torch = torch_cuda
+    md = bq.compute_mode.fp32_tc_cor
+    bf = bq.buffer(md, False); bf.allocate(4096, 64)
+    assert bq.qr_batch([], 4096, [], 64, [], 4096, 4096, 64, bf) == (0, [])          # empty batch
+    a = oracle.uniform_matrix(4096, 64, seed=3)
+    w = blocking(bq, torch, a, md)
+    for k in (1, 2):                                                               # below the chained schedule's minimum of three
+        b = Batch(bq, torch, [a] * k, md)
+        assert b.run(bq) == (0, [0] * k)
+        assert all(same(r, w) for r in b.results())
+    d = torch.zeros(64 * 64, dtype=torch.float32, device="cuda")
+    st, states = bq.qr_batch([d, d, d], 8, [d, d, d], 16, [d, d, d], 8, 8, 16, bf)    # n > m: every call reports it
+    assert st == 1 and states == [1, 1, 1]
+    with pytest.raises(ValueError):
+        bq.qr_batch([d], 8, [d, d], 8, [d], 8, 8, 8, bf)
+
+
+@pytest.mark.parametrize("m,n,k", [(1 << 17, 64, 6), (64 * 520, 128, 4), (9211, 51, 5)])
+def test_cpp_caller_of_qr_batch(bq, torch_cuda, m, n, k):
+    """tests/cpp/sample_batch.cpp: a C++ caller's loop of mtk::qr::qr calls over K matrices against one mtk::qr::qr_batch call --
+    every byte of every Q and R agrees (exit code 0)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp"), "-s", "sample_batch"])
+    out = subprocess.run([os.path.join(root, "tests", "cpp", "sample_batch"), str(m), str(n), str(k)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatching matrices: 0" in out.stdout

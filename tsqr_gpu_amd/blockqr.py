@@ -47,7 +47,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist", "tsqr_mi_qr_f32_dist_cb",
     "tsqr_mi_qr_f32_loop", "tsqr_mi_qr_f32_dist_fn", "tsqr_mi_qr_f32_dist_fn_loop", "tsqr_mi_qr_f32_dist_cb_loop",
     "tsqr_mi_qr_f16", "tsqr_mi_qr_f16_loop", "tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16",
-    "tsqr_mi_qr_f32_submit", "tsqr_mi_qr_f32_finish", "tsqr_mi_set_loop_depth",
+    "tsqr_mi_qr_f32_submit", "tsqr_mi_qr_f32_finish", "tsqr_mi_set_loop_depth", "tsqr_mi_qr_f32_batch",
 ]
 
 
@@ -60,9 +60,22 @@ class Ticket(ctypes.Structure):
                 ("wq", ctypes.c_void_p), ("wr", ctypes.c_void_p), ("stream", ctypes.c_void_p),
                 ("h_wl", ctypes.c_void_p), ("words", ctypes.c_void_p), ("words_dev", ctypes.c_void_p)]
 
-    def __del__(self):                    # the library holds the address of a ticket in flight: never let one go away unfinished
-        if self.pending == 1 and _lib is not None:
+    def __del__(self):
+        # The library holds the address of a ticket in flight, so one must not go away unfinished -- but finish belongs to the thread
+        # that submitted it (include/tsqr_mi.h), and a finaliser runs wherever the collector happens to be, possibly at interpreter
+        # shutdown: finish here only on the submitting thread of a live interpreter; otherwise say what went wrong.
+        if self.pending != 1:
+            return
+        import sys
+        import threading
+        if _lib is not None and not sys.is_finalizing() and getattr(self, "_tid", None) == threading.get_ident():
             _lib.tsqr_mi_qr_f32_finish(ctypes.byref(self))
+        else:
+            import warnings
+            warnings.warn("tsqr_gpu_amd: a Ticket in flight was dropped on another thread (or at shutdown) without finish(); "
+                          "call blockqr.finish(ticket) on the submitting thread", ResourceWarning, stacklevel=2)
+
+
 FP16_MODES = (compute_mode.fp16_notc, compute_mode.fp16_tc_nocor)     # io type half in the reference (src/tsqr.hpp:38-39)
 
 _lib = None
@@ -121,6 +134,8 @@ def lib():
     L.tsqr_mi_qr_f32_submit.argtypes = L.tsqr_mi_qr_f32.argtypes + [ctypes.POINTER(Ticket)]
     L.tsqr_mi_qr_f32_finish.restype = ci
     L.tsqr_mi_qr_f32_finish.argtypes = [ctypes.POINTER(Ticket)]
+    L.tsqr_mi_qr_f32_batch.restype = ci
+    L.tsqr_mi_qr_f32_batch.argtypes = [ci, ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp]
     L.tsqr_mi_set_loop_depth.restype = None
     L.tsqr_mi_set_loop_depth.argtypes = [ci]
     L.tsqr_mi_qr_f16.restype = ci
@@ -263,8 +278,10 @@ def submit(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthogona
         raise TypeError("submit() takes the fp32 I/O modes")
     if stream is None:
         stream = torch.cuda.current_stream()
+    import threading
     t = Ticket()
     t._keep = (q, r, a, bf, stream)
+    t._tid = threading.get_ident()
     st = lib().tsqr_mi_qr_f32_submit(int(mode), int(reorth), _ptr(q), ldq, _ptr(r), ldr, _ptr(a), lda, m, n,
                                      _ptr(bf.dwq), _ptr(bf.dwr), _ptr(bf.dw_reorth_r), _ptr(bf.dl), _ptr(bf.hl), stream.cuda_stream, ctypes.byref(t))
     if st < 0:
@@ -331,6 +348,42 @@ def bind_loop(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthog
         return st
     call._keep = keep
     return call
+
+
+def bind_batch(qs, ldq, rs, ldr, as_, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
+    """mtk::qr::qr_batch (tsqr_mi_qr_f32_batch): qs, rs, as_ are equally long sequences of float32 tensors, one (q, r, a) triple per
+    matrix, all of the shape m x n with the shared leading dimensions.  Returns a callable: call() factors every matrix (blocking) and
+    returns (first non-zero state, [state of every call]).  The tensors, the buffer and the stream must stay alive while it is in use."""
+    import torch
+    mode = bf.mode if mode is None else compute_mode(mode)
+    reorth = bf.reorthogonalize if reorthogonalize is None else bool(reorthogonalize)
+    if mode in FP16_MODES:
+        raise TypeError("the batch entry takes the fp32 I/O modes")
+    if not (len(qs) == len(rs) == len(as_)):
+        raise ValueError("qr_batch: q, r and a must name the same number of matrices")
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    count = len(as_)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    arr = lambda ts: (vp * max(count, 1))(*[t.data_ptr() for t in ts])
+    pq, pr, pa = arr(qs), arr(rs), arr(as_)
+    states = (ci * max(count, 1))()
+    fn = lib().tsqr_mi_qr_f32_batch
+    args = (ci(count), ci(int(mode)), ci(int(reorth)), pq, sz(ldq), pr, sz(ldr), pa, sz(lda), sz(m), sz(n),
+            vp(_ptr(bf.dwq)), vp(_ptr(bf.dwr)), vp(_ptr(bf.dw_reorth_r)), vp(_ptr(bf.dl)), vp(_ptr(bf.hl)), vp(stream.cuda_stream), states)
+
+    def call():
+        st = fn(*args)
+        if st < 0:
+            raise RuntimeError("tsqr_mi_qr_f32_batch failed: %s" % last_error())
+        return st, list(states[:count])
+    call._keep = (list(qs), list(rs), list(as_), bf, stream, pq, pr, pa, states)
+    return call
+
+
+def qr_batch(qs, ldq, rs, ldr, as_, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
+    """One-shot form of bind_batch(): returns (first non-zero state, [states])."""
+    return bind_batch(qs, ldq, rs, ldr, as_, lda, m, n, bf, stream, mode, reorthogonalize)()
 
 
 def set_tuning(level0_waves=0, tree_chunks_per_wave=0):

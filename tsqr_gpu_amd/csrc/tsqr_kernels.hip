@@ -2469,6 +2469,15 @@ __global__ __launch_bounds__(1024) void rmul64_kernel(float* __restrict__ r, siz
 __global__ void host_flag_kernel(unsigned* __restrict__ host_flag, unsigned seq) {
 	*reinterpret_cast<volatile unsigned*>(host_flag) = seq;
 }
+// row-partitioned loop entries: the eligibility vote of a chained stream travels with the first Gram all-reduce of the stream (one more
+// double behind the row count); set_f64_kernel writes this rank's 1.0, vote_out_kernel puts the all-reduced count (<= 255 ranks) and a
+// 24-bit sequence number into ONE pinned host word
+__global__ void set_f64_kernel(double* __restrict__ p, double v) { *p = v; }
+__global__ void vote_out_kernel(const double* __restrict__ count, unsigned* __restrict__ host_word, unsigned seq) {
+	const double v = *count;
+	const unsigned n = (v >= 0.0 && v < 255.5) ? (unsigned)(v + 0.5) : 255u;
+	*reinterpret_cast<volatile unsigned*>(host_word) = ((seq & 0xffffffu) << 8) | n;
+}
 
 // fp16 I/O modes (reference mtk::qr::qr<fp16_notc | fp16_tc_nocor>: io type half, src/tsqr.hpp:38-39): the boundary converts, the
 // factorisation runs on the fp32 pipeline.  One thread moves eight consecutive rows of one column: a 16-byte fp16 access when the

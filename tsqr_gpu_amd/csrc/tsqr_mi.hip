@@ -1328,28 +1328,124 @@ static int finish_impl(const CallEnv& env, tsqr_mi_ticket* t) {
 }
 int tsqr_mi_qr_f32_finish(tsqr_mi_ticket* t) { return finish_impl(CallEnv{}, t); }
 
-// `count` calls with the same arguments as a stream: call i + 1 is submitted before call i is finished; the completion word of call i
-// is raised by the first kernel of call i + 1 (stream order: it starts when call i has finished), only the last call carries a
-// completion kernel of its own.  Row-partitioned calls: every rank takes the same verdicts (they come from the all-reduced Gram
-// matrix), hence the same path through this loop and the same order of collectives.
+// ---- a stream of calls: `count` factorisations of ONE shape on one stream with one set of work buffers.  The loop entries pass the same
+// (q, r, a) every time (the reference's speed protocol, src/test.cu:299-309), the batch entry one triple per call (a caller with many
+// matrices, reference README.md:52-87 in a loop).  Mats hides the difference; Call carries what all calls of the stream share. ----
+constexpr int NOT_MINE = -1000000;                     // "this schedule is not for this stream of calls; nothing enqueued" (not a hipError_t)
+struct Mats {
+	float* const* qs = nullptr; float* const* rs = nullptr; float* const* as = nullptr;   // host arrays of device pointers (batch entries) ...
+	float* q0 = nullptr; float* r0 = nullptr; float* a0 = nullptr;                        // ... or one triple for every call (loop entries)
+	int* states = nullptr;                               // optional: the state of every call
+	bool same() const { return as == nullptr; }
+	float* q(int i) const { return qs ? qs[i] : q0; }
+	float* r(int i) const { return rs ? rs[i] : r0; }
+	float* a(int i) const { return as ? as[i] : a0; }
+	void state(int i, int st) const { if (states) states[i] = st; }
+	Mats from(int i) const {
+		Mats t = *this;
+		if (!same()) { t.qs += i; t.rs += i; t.as += i; }
+		if (states) t.states += i;
+		return t;
+	}
+};
+struct Call { int mode, reorth; size_t ldq, ldr, lda, m, n; void* wq; void* wr; unsigned* h_wl; void* stream; };
+
+// The chained schedules launch the Gram pass of call i + 1 BEFORE the apply pass of call i, in the launch that writes R of call i.  That
+// is the blocking order only if no output of call i is an input of call i + 1: Q(i) and R(i) must not overlap A(i + 1).  (A loop over one
+// triple factored in place, q == a, fails this test: call i + 1 of the blocking loop factors the Q that call i left there.)
+static bool chain_order_safe(const Mats& mt, int count, const Call& cl, size_t esz = sizeof(float)) {
+	auto overlap = [](const void* p, size_t pb, const void* s, size_t sb) {
+		const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(s);
+		return a0 < b0 + sb && b0 < a0 + pb;
+	};
+	const size_t qb = ((cl.n - 1) * cl.ldq + cl.m) * esz, ab = ((cl.n - 1) * cl.lda + cl.m) * esz, rb = ((cl.n - 1) * cl.ldr + cl.n) * esz;
+	const int pairs = mt.same() ? 1 : count - 1;
+	for (int i = 0; i < pairs; i++) {
+		const int j = mt.same() ? i : i + 1;
+		if (overlap(mt.q(i), qb, mt.a(j), ab) || overlap(mt.r(i), rb, mt.a(j), ab)) return false;
+	}
+	return true;
+}
+
+// spin on a completion word of the pinned words (the stream is looked at now and then so that a failed launch cannot hang the caller)
+static int wait_word(volatile unsigned* word, unsigned seq, hipStream_t st) {
+	for (;;) {
+		for (int k = 0; k < 20000; k++) {
+			if (*word == seq) return 0;
+			__builtin_ia32_pause();
+		}
+		const hipError_t e = hipStreamQuery(st);
+		if (e == hipSuccess) return 0;
+		if (e != hipErrorNotReady) HIPCHK(e);
+	}
+}
+
+// one call of the stream as a plain blocking call with its whole ladder
+static int blocking_one(const CallEnv& env, const Mats& mt, int i, const Call& cl) {
+	if (!env.dist)
+		return tsqr_mi_qr_f32(cl.mode, cl.reorth, mt.q(i), cl.ldq, mt.r(i), cl.ldr, mt.a(i), cl.lda, cl.m, cl.n, cl.wq, cl.wr, nullptr, nullptr, cl.h_wl, cl.stream);
+	Ctx cc;
+	cc.comm = env.comm;
+	return qr_dist_common(cc, cl.mode, cl.reorth, mt.q(i), cl.ldq, mt.r(i), cl.ldr, mt.a(i), cl.lda, cl.m, cl.n, cl.wq, cl.wr, env.nranks, cl.stream);
+}
+
+// Call i of a chained stream was rejected by the bf16-split level: its apply pass skipped itself and A(i) is intact.  Everything of call
+// i + 1 is enqueued behind it.  Drain the stream; call i gets its whole ladder as a blocking call; call i + 1 STANDS when it was accepted
+// (it may have been factored in place -- an accepted call is never redone) and gets its ladder otherwise.  *done = calls dealt with; the
+// caller goes on from there.  A loop over one triple would see every further attempt rejected as well: the rest of its count runs as
+// blocking calls.  (Row-partitioned: the verdicts come from the all-reduced matrix -- every rank walks through here alike.)
+static int rejected_tail(const CallEnv& env, const Mats& mt, int count, const Call& cl, int i, volatile unsigned* words, hipStream_t st, int* done) {
+	HIPCHK(hipStreamSynchronize(st));
+	prof_collect();
+	const bool next = i + 1 < count, next_rejected = next && words[4 * ((i + 1) & 1)] != 0;     // (read before a blocking call reuses the words)
+	int first = 0;
+	if (mt.same()) {
+		for (int k = i; k < count; k++) {
+			const int s = blocking_one(env, mt, k, cl);
+			if (s < 0) return s;
+			mt.state(k, s);
+			if (s && !first) first = s;
+		}
+		*done = count;
+		return first;
+	}
+	int s = blocking_one(env, mt, i, cl);
+	if (s < 0) return s;
+	mt.state(i, s);
+	first = s;
+	*done = i + 1;
+	if (next) {
+		s = 0;
+		if (next_rejected) { s = blocking_one(env, mt, i + 1, cl); if (s < 0) return s; }
+		mt.state(i + 1, s);
+		if (s && !first) first = s;
+		*done = i + 2;
+	}
+	return first;
+}
+
 // The stream for full 64-column matrices of up to 2^20 rows (the shapes gram_blk_kernel takes): the R-factor chain of call i (reduction,
 // Cholesky, verdict) runs inside the launch that is the Gram pass of call i + 1 (gram_blk_chain_kernel), so a call costs its two
 // streaming passes and nothing else:
 //     gram(0) | [chain(0) + gram(1)]  apply(0) | [chain(1) + gram(2)]  apply(1) | ... | reduce, Cholesky (launches of their own)  apply(last)
-// Two sets of Gram partials (wr), everything else as in the plain stream: verdict words alternate, the completion word of call i is
-// raised by the first kernel behind apply(i).  Returns -2 when the shape / settings are not the ones this schedule is for (nothing
-// enqueued).  A rejected verdict (never seen by a well-conditioned loop) drains the stream and finishes the count with blocking calls.
-static int stream_of_calls_chained(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
-                                   size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
-	const int engine = engine_of(mode);
-	if (count < 3 || engine < 0 || reorth || n != PW || m % 128 != 0 || m > ((size_t)1 << 20) || lda % 4 != 0 || lda > ((size_t)1 << 24) ||
-	    lda < m || ldq < m || ldr < n || (reinterpret_cast<uintptr_t>(a) & 15) != 0)
-		return -2;
+// Two sets of Gram partials (wr); verdict words alternate between the halves of the pinned words; the completion word of call i is raised
+// by the first kernel behind apply(i).  Returns NOT_MINE when the shape / settings / operand order are not the ones this schedule is for
+// (nothing enqueued).  A rejected verdict ends the schedule at that call (rejected_tail); *done tells the caller how far the stream got.
+static int chained64(const Mats& mt, int count, const Call& cl, int* done) {
+	*done = 0;
+	const size_t m = cl.m, n = cl.n, lda = cl.lda, ldq = cl.ldq, ldr = cl.ldr;
+	const int engine = engine_of(cl.mode);
+	if (count < 3 || engine < 0 || cl.reorth || n != PW || m % 128 != 0 || m > ((size_t)1 << 20) || lda % 4 != 0 || lda > ((size_t)1 << 24) ||
+	    lda < m || ldq < m || ldr < n)
+		return NOT_MINE;
+	for (int i = 0; i < (mt.same() ? 1 : count); i++)
+		if ((reinterpret_cast<uintptr_t>(mt.a(i)) & 15) != 0) return NOT_MINE;
+	if (!chain_order_safe(mt, count, cl)) return NOT_MINE;
 	Ctx c;
-	init_ctx(c, wq_v, wr_v, m, n, stream);
+	init_ctx(c, cl.wq, cl.wr, m, n, cl.stream);
 	c.rows_global = (double)m;
-	resolve_host_sig(c, h_wl, m);
-	if (!(c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug)) return -2;
+	resolve_host_sig(c, cl.h_wl, m);
+	if (!(c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !g_set.debug)) return NOT_MINE;
 	c.fold_cor = (engine == 1);
 	static DevOnce attr;
 	if (attr.need(c.dev)) {
@@ -1367,14 +1463,14 @@ static int stream_of_calls_chained(int count, int mode, int reorth, float* q, si
 	unsigned* announce = nullptr; unsigned announce_seq = 0;             // completion word the next launch raises
 	auto gram_args = [&](int i) {
 		tsqrmi::GramArgs ga{};
-		ga.a = a; ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = nchunks; ga.cpw = g.cpw; ga.nwaves = g.nwaves;
+		ga.a = mt.a(i); ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = nchunks; ga.cpw = g.cpw; ga.nwaves = g.nwaves;
 		ga.part = part[i & 1];
 		ga.announce = announce; ga.announce_seq = announce_seq; announce = nullptr;
 		return ga;
 	};
-	auto chol_args = [&](int i, float* rr, size_t ld) {
+	auto chol_args = [&](int i) {
 		tsqrmi::CholArgs ca{};
-		ca.r = rr; ca.ldr = ld; ca.z = c.wq + c.L.z;
+		ca.r = mt.r(i); ca.ldr = ldr; ca.z = c.wq + c.L.z;
 		ca.status = c.status_dev(i & 1);
 		ca.host_status = c.hsig.dev + 4 * (i & 1);
 		ca.gsum = c.gsum();
@@ -1386,20 +1482,22 @@ static int stream_of_calls_chained(int count, int mode, int reorth, float* q, si
 	auto step = [&](int i) -> int {
 		if (i + 1 < count) {
 			tsqrmi::ChainArgs ch{};
-			ch.chol = chol_args(i, r, ldr);
+			ch.chol = chol_args(i);
 			ch.part = part[i & 1]; ch.nparts = nparts; ch.ticket = ticket; ch.nred = nred;
+			ProfScope ps(KC_GRAM, c.st);
 			hipLaunchKernelGGL(tsqrmi::gram_blk_chain_kernel, dim3(nred + nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(i + 1), ch);
 		} else {
 			// the last call: no Gram pass left to hide behind -- the chain as launches of its own (and the completion word of the call
 			// before, which no Gram kernel is there to raise)
 			if (announce) { hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, announce, announce_seq); announce = nullptr; }
+			ProfScope ps(KC_CHOL, c.st);
 			hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nred), dim3(256), 0, c.st, c.gsum(), part[i & 1], nparts, nelem, (double)m,
 			                   nullptr, (size_t)0, nullptr, 0);
-			hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, chol_args(i, r, ldr));
+			hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, chol_args(i));
 		}
 		HIPCHK(hipGetLastError());
 		c.slot = i & 1;
-		const int rc = apply_rinv(c, engine, q, ldq, a, lda, r, ldr, m, n, /*z_ready=*/true, c.status_dev(i & 1));
+		const int rc = apply_rinv(c, engine, mt.q(i), ldq, mt.a(i), lda, mt.r(i), ldr, m, n, /*z_ready=*/true, c.status_dev(i & 1));
 		if (rc) return rc;
 		unsigned sq = ++g_seq;
 		if (sq == 0) sq = ++g_seq;
@@ -1410,36 +1508,23 @@ static int stream_of_calls_chained(int count, int mode, int reorth, float* q, si
 		HIPCHK(hipGetLastError());
 		return 0;
 	};
-	hipLaunchKernelGGL(tsqrmi::gram_blk_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(0));
+	{
+		ProfScope ps(KC_GRAM, c.st);
+		hipLaunchKernelGGL(tsqrmi::gram_blk_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(0));
+	}
 	HIPCHK(hipGetLastError());
 	int rc = step(0);
 	if (rc) return rc;
 	for (int i = 0; i < count; i++) {
 		if (i + 1 < count) { rc = step(i + 1); if (rc) return rc; }
-		// wait for call i (completion word; the stream is looked at now and then so that a failed launch cannot hang the caller)
-		for (bool done = false; !done;) {
-			for (int k = 0; k < 20000 && !done; k++) {
-				done = (words[4 * (i & 1) + 3] == seq[i & 1]);
-				if (!done) __builtin_ia32_pause();
-			}
-			if (!done) {
-				const hipError_t e = hipStreamQuery(c.st);
-				if (e == hipSuccess) done = true;
-				else if (e != hipErrorNotReady) HIPCHK(e);
-			}
-		}
-		if (words[4 * (i & 1)] != 0) {
-			// call i was rejected by the bf16-split level (its apply pass skipped itself): drain, then this call and the rest of the
-			// count as blocking calls with their whole ladder
-			HIPCHK(hipStreamSynchronize(c.st));
-			for (int k = i; k < count; k++) {
-				const int st = tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, nullptr, nullptr, h_wl, stream);
-				if (st) return st;
-			}
-			return TSQR_MI_SUCCESS;
-		}
+		rc = wait_word(words + 4 * (i & 1) + 3, seq[i & 1], c.st);
+		if (rc) return rc;
+		if (words[4 * (i & 1)] != 0) return rejected_tail(CallEnv{}, mt, count, cl, i, words, c.st, done);
+		mt.state(i, TSQR_MI_SUCCESS);
+		*done = i + 1;
 	}
 	t_last_engine = 3;
+	prof_collect();
 	return TSQR_MI_SUCCESS;
 }
 
@@ -1447,19 +1532,23 @@ static int stream_of_calls_chained(int count, int mode, int reorth, float* q, si
 // two-block factorisation of call i (45 us on one workgroup) rides in the Gram launch of call i + 1 (gram_wide_chain_kernel); the
 // reduction of the partials stays a launch of its own in front of it:
 //     gram(0) reduce(0) | [chol(0) + gram(1)]  reduce(1)  apply(0) | [chol(1) + gram(2)]  reduce(2)  apply(1) | ... | chol(last)  apply(last)
-// Returns -2 when the call is not one for it (nothing enqueued); a rejected verdict drains the stream and finishes the count with
-// blocking calls (which fall back to 64-column panels and overwrite A, as the blocking call does).
-static int stream_of_calls_wide_chained(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
-                                        size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
-	const int engine = engine_of(mode);
-	if (count < 3 || engine < 0 || reorth || n != 2 * PW || m < n || m % 64 != 0 || m / 64 < 2 * (size_t)WIDE_MAX_WGS || lda > ((size_t)1 << 23) ||
-	    lda < m || ldq < m || ldr < n || lda % 4 != 0 || (reinterpret_cast<uintptr_t>(a) & 15) != 0)
-		return -2;
+// Returns NOT_MINE when the stream is not one for it (nothing enqueued); a rejected verdict ends the schedule at that call (rejected_tail:
+// its blocking call falls back to 64-column panels and overwrites A, as the blocking call does).
+static int chained128(const Mats& mt, int count, const Call& cl, int* done) {
+	*done = 0;
+	const size_t m = cl.m, n = cl.n, lda = cl.lda, ldq = cl.ldq, ldr = cl.ldr;
+	const int engine = engine_of(cl.mode);
+	if (count < 3 || engine < 0 || cl.reorth || n != 2 * PW || m < n || m % 64 != 0 || m / 64 < 2 * (size_t)WIDE_MAX_WGS || lda > ((size_t)1 << 23) ||
+	    lda < m || ldq < m || ldr < n || lda % 4 != 0)
+		return NOT_MINE;
+	for (int i = 0; i < (mt.same() ? 1 : count); i++)
+		if ((reinterpret_cast<uintptr_t>(mt.a(i)) & 15) != 0) return NOT_MINE;
+	if (!chain_order_safe(mt, count, cl)) return NOT_MINE;
 	Ctx c;
-	init_ctx(c, wq_v, wr_v, m, n, stream);
+	init_ctx(c, cl.wq, cl.wr, m, n, cl.stream);
 	c.rows_global = (double)m;
-	resolve_host_sig(c, h_wl, m);
-	if (!(c.wide && c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug)) return -2;
+	resolve_host_sig(c, cl.h_wl, m);
+	if (!(c.wide && c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !g_set.debug)) return NOT_MINE;
 	static DevOnce attr;
 	if (attr.need(c.dev)) {
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GW_LDS_BYTES));
@@ -1475,35 +1564,44 @@ static int stream_of_calls_wide_chained(int count, int mode, int reorth, float* 
 	volatile unsigned* words = reinterpret_cast<volatile unsigned*>(c.hsig.host);
 	unsigned seq[2] = {0, 0};
 	unsigned* announce = nullptr; unsigned announce_seq = 0;
-	auto gram_args = [&]() {
+	auto gram_args = [&](int i) {
 		tsqrmi::GramWideArgs ga{};
-		ga.a = a; ga.lda = lda; ga.m = m; ga.n = (int)n; ga.blk0 = 0; ga.nblk = nblk; ga.part = part;
+		ga.a = mt.a(i); ga.lda = lda; ga.m = m; ga.n = (int)n; ga.blk0 = 0; ga.nblk = nblk; ga.part = part;
 		ga.announce = announce; ga.announce_seq = announce_seq; announce = nullptr;
 		return ga;
 	};
 	auto chol_args = [&](int i) {
 		tsqrmi::CholWideArgs wa{};
-		wa.gsum = gsum; wa.r = r; wa.ldr = ldr; wa.n = (int)n; wa.zf1 = c.wq + c.L.z; wa.zf2 = zf2; wa.zw = zw;
+		wa.gsum = gsum; wa.r = mt.r(i); wa.ldr = ldr; wa.n = (int)n; wa.zf1 = c.wq + c.L.z; wa.zf2 = zf2; wa.zw = zw;
 		wa.st1 = c.status_dev(2); wa.st2 = c.status_dev(3); wa.status = c.status_dev(i & 1);
 		wa.host_status = c.hsig.dev + 4 * (i & 1);
 		wa.rows = (double)m; wa.scond_floor = g_set.bf16_scond_floor;
 		return wa;
 	};
 	auto reduce = [&]() {
+		ProfScope ps(KC_CHOL, c.st);
 		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, gsum, part, wgs, nelem, (double)m, nullptr, (size_t)0, nullptr, 0);
 	};
 	auto step = [&](int i) -> int {
 		if (i + 1 < count) {
-			hipLaunchKernelGGL(tsqrmi::gram_wide_chain_kernel, dim3(1 + wgs), dim3(512), tsqrmi::GWC_LDS_BYTES, c.st, gram_args(), chol_args(i));
+			{
+				ProfScope ps(KC_GRAM, c.st);
+				hipLaunchKernelGGL(tsqrmi::gram_wide_chain_kernel, dim3(1 + wgs), dim3(512), tsqrmi::GWC_LDS_BYTES, c.st, gram_args(i + 1), chol_args(i));
+			}
 			reduce();
 		} else {
 			if (announce) { hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, announce, announce_seq); announce = nullptr; }
+			ProfScope ps(KC_CHOL, c.st);
 			hipLaunchKernelGGL(tsqrmi::chol_wide_kernel, dim3(1), dim3(1024), 0, c.st, chol_args(i));
 		}
 		HIPCHK(hipGetLastError());
 		tsqrmi::ApplyArgs aa{};
-		aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = zw; aa.skip_status = c.status_dev(i & 1);
-		const int rc = (engine == 0) ? launch_apply_wide<0>(c, aa) : (engine == 1 ? launch_apply_wide<1>(c, aa) : launch_apply_wide<2>(c, aa));
+		aa.a = mt.a(i); aa.lda = lda; aa.q = mt.q(i); aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = zw; aa.skip_status = c.status_dev(i & 1);
+		int rc;
+		{
+			ProfScope ps(KC_APPLY, c.st);
+			rc = (engine == 0) ? launch_apply_wide<0>(c, aa) : (engine == 1 ? launch_apply_wide<1>(c, aa) : launch_apply_wide<2>(c, aa));
+		}
 		if (rc) return rc;
 		HIPCHK(hipGetLastError());
 		unsigned sq = ++g_seq;
@@ -1515,34 +1613,24 @@ static int stream_of_calls_wide_chained(int count, int mode, int reorth, float* 
 		HIPCHK(hipGetLastError());
 		return 0;
 	};
-	hipLaunchKernelGGL((tsqrmi::gram_wide_kernel<true>), dim3(wgs), dim3(512), tsqrmi::GW_LDS_BYTES, c.st, gram_args());
+	{
+		ProfScope ps(KC_GRAM, c.st);
+		hipLaunchKernelGGL((tsqrmi::gram_wide_kernel<true>), dim3(wgs), dim3(512), tsqrmi::GW_LDS_BYTES, c.st, gram_args(0));
+	}
 	reduce();
 	HIPCHK(hipGetLastError());
 	int rc = step(0);
 	if (rc) return rc;
 	for (int i = 0; i < count; i++) {
 		if (i + 1 < count) { rc = step(i + 1); if (rc) return rc; }
-		for (bool done = false; !done;) {
-			for (int k = 0; k < 20000 && !done; k++) {
-				done = (words[4 * (i & 1) + 3] == seq[i & 1]);
-				if (!done) __builtin_ia32_pause();
-			}
-			if (!done) {
-				const hipError_t e = hipStreamQuery(c.st);
-				if (e == hipSuccess) done = true;
-				else if (e != hipErrorNotReady) HIPCHK(e);
-			}
-		}
-		if (words[4 * (i & 1)] != 0) {
-			HIPCHK(hipStreamSynchronize(c.st));
-			for (int k = i; k < count; k++) {
-				const int st = tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, nullptr, nullptr, h_wl, stream);
-				if (st) return st;
-			}
-			return TSQR_MI_SUCCESS;
-		}
+		rc = wait_word(words + 4 * (i & 1) + 3, seq[i & 1], c.st);
+		if (rc) return rc;
+		if (words[4 * (i & 1)] != 0) return rejected_tail(CallEnv{}, mt, count, cl, i, words, c.st, done);
+		mt.state(i, TSQR_MI_SUCCESS);
+		*done = i + 1;
 	}
 	t_last_engine = 5;
+	prof_collect();
 	return TSQR_MI_SUCCESS;
 }
 
@@ -1551,26 +1639,22 @@ static int stream_of_calls_wide_chained(int count, int mode, int reorth, float* 
 //     gram(0) reduce(0) allreduce(0) | [chol(0) + gram(1)]  reduce(1) allreduce(1)  apply(0) | [chol(1) + gram(2)]  reduce(2) allreduce(2)  apply(1) | ...
 //     ... | chol(last) (a launch of its own)  apply(last)
 // -- the Cholesky launch (17.5 us + its ramp) leaves the critical path of every call but the last.  The collectives are enqueued in a
-// different order than by the plain stream (allreduce(i + 1) before apply(i)), so ALL ranks must take this schedule or none: the
-// ranks agree by one all-reduce of their eligibility flags per loop call.  Returns -2 (nothing but that agreement enqueued) when any
-// rank is not eligible.  A rejected verdict -- the same on every rank -- drains the stream and finishes the count with blocking calls.
-static int stream_of_calls_dist_chained(const CallEnv& env, int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
-                                        size_t m, size_t n, void* wq_v, void* wr_v, void* stream) {
-	const int engine = engine_of(mode);
-	if (engine < 0 || m == 0 || n == 0 || env.nranks < 1) return -2;       // (the plain path reports these)
+// different order than by the plain stream (allreduce(i + 1) before apply(i)), so ALL ranks must take this schedule or none.  The vote costs
+// no collective of its own: the first all-reduce of the stream -- the Gram tiles of call 0, the same launch in either schedule -- carries one
+// more double, 1.0 from every rank that is eligible (a rank that is not sends zeros instead of a Gram pass: the result is then thrown away);
+// a one-thread kernel behind it puts the count into the pinned words and the host decides when it sees it, with Gram pass and all-reduce of
+// call 0 already done.  Returns NOT_MINE when any rank is not eligible (the stream is then idle and holds nothing of this call).
+// A rejected verdict -- the same on every rank -- ends the schedule at that call (rejected_tail).
+static int chained_dist(const CallEnv& env, const Mats& mt, int count, const Call& cl, int* done) {
+	*done = 0;
+	const size_t m = cl.m, n = cl.n, lda = cl.lda, ldq = cl.ldq, ldr = cl.ldr;
+	const int engine = engine_of(cl.mode);
+	if (engine < 0 || m == 0 || n == 0 || n > PW || env.nranks < 1 || env.nranks > 255) return NOT_MINE;   // (conditions every rank shares; the plain path reports errors)
 	Ctx c;
-	env_ctx(c, env, wq_v, wr_v, m, n, nullptr, stream, /*keep_in_flight=*/false);
-	const bool mine = !reorth && n == PW && m % 128 == 0 && m <= ((size_t)1 << 20) && lda % 4 == 0 && lda <= ((size_t)1 << 24) && lda >= m && ldq >= m &&
-	                  ldr >= n && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug;
-	{
-		double h = mine ? 1.0 : 0.0;
-		HIPCHK(hipMemcpyAsync(c.gsum(), &h, sizeof(double), hipMemcpyHostToDevice, c.st));
-		HIPCHK(hipStreamSynchronize(c.st));              // (h is a stack variable)
-		if (c.comm.allreduce_f64(c.gsum(), 1, c.st)) { t_last_error = "all-reduce of the schedule flags failed"; return -1; }
-		HIPCHK(hipMemcpyAsync(&h, c.gsum(), sizeof(double), hipMemcpyDeviceToHost, c.st));
-		HIPCHK(hipStreamSynchronize(c.st));
-		if (h != (double)env.nranks) return -2;
-	}
+	env_ctx(c, env, cl.wq, cl.wr, m, n, nullptr, cl.stream, /*keep_in_flight=*/false);
+	bool mine = c.hsig.dev && !cl.reorth && n == PW && m % 128 == 0 && m <= ((size_t)1 << 20) && lda % 4 == 0 && lda <= ((size_t)1 << 24) && lda >= m && ldq >= m &&
+	            ldr >= n && c.policy == 0 && c.gram_level == 2 && !g_set.debug && chain_order_safe(mt, count, cl);
+	for (int i = 0; mine && i < (mt.same() ? 1 : count); i++) mine = (reinterpret_cast<uintptr_t>(mt.a(i)) & 15) == 0;
 	c.fold_cor = (engine == 1);
 	static DevOnce attr;
 	if (attr.need(c.dev)) {
@@ -1578,21 +1662,21 @@ static int stream_of_calls_dist_chained(const CallEnv& env, int count, int mode,
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tsqrmi::gram_blk_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tsqrmi::GB_LDS_BYTES));
 		attr.done(c.dev);
 	}
-	const GramPlan g = gram_plan(m, n);
+	const GramPlan g = gram_plan(m, PW);
 	const int nchunks = (int)(m / 128), nparts = std::min(nchunks, g.nblocks), nelem = 10 * 256;
 	double* part = reinterpret_cast<double*>(c.wr);
 	volatile unsigned* words = reinterpret_cast<volatile unsigned*>(c.hsig.host);
 	unsigned seq[2] = {0, 0};
 	unsigned* announce = nullptr; unsigned announce_seq = 0;
-	auto gram_args = [&]() {
+	auto gram_args = [&](int i) {
 		tsqrmi::GramArgs ga{};
-		ga.a = a; ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = nchunks; ga.cpw = g.cpw; ga.nwaves = g.nwaves; ga.part = part;
+		ga.a = mt.a(i); ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = nchunks; ga.cpw = g.cpw; ga.nwaves = g.nwaves; ga.part = part;
 		ga.announce = announce; ga.announce_seq = announce_seq; announce = nullptr;
 		return ga;
 	};
 	auto chol_args = [&](int i) {
 		tsqrmi::CholArgs ca{};
-		ca.r = r; ca.ldr = ldr; ca.z = c.wq + c.L.z;
+		ca.r = mt.r(i); ca.ldr = ldr; ca.z = c.wq + c.L.z;
 		ca.status = c.status_dev(i & 1);
 		ca.host_status = c.hsig.dev + 4 * (i & 1);
 		ca.gsum = c.gsum();
@@ -1601,29 +1685,76 @@ static int stream_of_calls_dist_chained(const CallEnv& env, int count, int mode,
 		ca.n = (int)n; ca.NT = 4; ca.level = 2; ca.scond_floor = g_set.bf16_scond_floor;
 		return ca;
 	};
-	auto reduce_allreduce = [&]() -> int {               // partials of the Gram pass just enqueued -> summed tiles + row count, over all ranks
-		hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, c.gsum(), part, nparts, nelem, (double)m,
-		                   nullptr, (size_t)0, nullptr, 0);
+	auto reduce_allreduce = [&](int extra) -> int {      // partials of the Gram pass just enqueued -> summed tiles + row count (+ `extra` doubles), over all ranks
+		{
+			ProfScope ps(KC_CHOL, c.st);
+			hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3(nelem / 16), dim3(256), 0, c.st, c.gsum(), part, nparts, nelem, (double)m,
+			                   nullptr, (size_t)0, nullptr, 0);
+		}
 		HIPCHK(hipGetLastError());
-		if (c.comm.allreduce_f64(c.gsum(), (size_t)nelem + 1, c.st)) { t_last_error = "all-reduce of the Gram tiles failed"; return -1; }
+		if (extra) hipLaunchKernelGGL(tsqrmi::set_f64_kernel, dim3(1), dim3(1), 0, c.st, c.gsum() + nelem + 1, 1.0);
+		ProfScope ps(KC_MISC, c.st);
+		if (c.comm.allreduce_f64(c.gsum(), (size_t)nelem + 1 + extra, c.st)) { t_last_error = "all-reduce of the Gram tiles failed"; return -1; }
 		return 0;
 	};
+	// ---- call 0 up to its all-reduce, with the vote in the payload ----
+	int rc = 0;
+	if (mine) {
+		{
+			ProfScope ps(KC_GRAM, c.st);
+			hipLaunchKernelGGL(tsqrmi::gram_blk_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(0));
+		}
+		HIPCHK(hipGetLastError());
+		rc = reduce_allreduce(1);
+	} else {
+		HIPCHK(hipMemsetAsync(c.gsum(), 0, sizeof(double) * ((size_t)nelem + 2), c.st));
+		if (c.comm.allreduce_f64(c.gsum(), (size_t)nelem + 2, c.st)) { t_last_error = "all-reduce of the schedule flags failed"; rc = -1; }
+	}
+	if (rc) return rc;
+	if (c.hsig.dev) {
+		unsigned vs = ++g_seq;
+		if ((vs & 0xffffffu) == 0) vs = ++g_seq;
+		words[8] = 0;
+		hipLaunchKernelGGL(tsqrmi::vote_out_kernel, dim3(1), dim3(1), 0, c.st, c.gsum() + nelem + 1, c.hsig.dev + 8, vs);
+		HIPCHK(hipGetLastError());
+		unsigned w = 0;
+		for (;;) {
+			bool seen = false;
+			for (int k = 0; k < 20000 && !seen; k++) {
+				w = words[8];
+				seen = (w >> 8) == (vs & 0xffffffu);
+				if (!seen) __builtin_ia32_pause();
+			}
+			if (seen) break;
+			const hipError_t e = hipStreamQuery(c.st);
+			if (e == hipSuccess) { w = words[8]; break; }
+			if (e != hipErrorNotReady) HIPCHK(e);
+		}
+		if ((int)(w & 0xffu) != env.nranks || (w >> 8) != (vs & 0xffffffu)) { prof_collect(); return NOT_MINE; }
+	} else {                                             // (no pinned words on this rank: it voted "no"; it still has to leave with an idle stream)
+		HIPCHK(hipStreamSynchronize(c.st));
+		return NOT_MINE;
+	}
 	auto step = [&](int i) -> int {
 		if (i + 1 < count) {
 			tsqrmi::ChainArgs ch{};
 			ch.chol = chol_args(i); ch.direct = 1;
-			hipLaunchKernelGGL(tsqrmi::gram_blk_chain_kernel, dim3(1 + nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(), ch);
+			{
+				ProfScope ps(KC_GRAM, c.st);
+				hipLaunchKernelGGL(tsqrmi::gram_blk_chain_kernel, dim3(1 + nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args(i + 1), ch);
+			}
 			HIPCHK(hipGetLastError());
-			const int rc = reduce_allreduce();
-			if (rc) return rc;
+			const int rc2 = reduce_allreduce(0);
+			if (rc2) return rc2;
 		} else {
 			if (announce) { hipLaunchKernelGGL(tsqrmi::host_flag_kernel, dim3(1), dim3(1), 0, c.st, announce, announce_seq); announce = nullptr; }
+			ProfScope ps(KC_CHOL, c.st);
 			hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, chol_args(i));
 			HIPCHK(hipGetLastError());
 		}
 		c.slot = i & 1;
-		const int rc = apply_rinv(c, engine, q, ldq, a, lda, r, ldr, m, n, /*z_ready=*/true, c.status_dev(i & 1));
-		if (rc) return rc;
+		const int rc2 = apply_rinv(c, engine, mt.q(i), ldq, mt.a(i), lda, mt.r(i), ldr, m, n, /*z_ready=*/true, c.status_dev(i & 1));
+		if (rc2) return rc2;
 		unsigned sq = ++g_seq;
 		if (sq == 0) sq = ++g_seq;
 		seq[i & 1] = sq;
@@ -1633,83 +1764,106 @@ static int stream_of_calls_dist_chained(const CallEnv& env, int count, int mode,
 		HIPCHK(hipGetLastError());
 		return 0;
 	};
-	hipLaunchKernelGGL(tsqrmi::gram_blk_kernel, dim3(nparts), dim3(256), tsqrmi::GB_LDS_BYTES, c.st, gram_args());
-	HIPCHK(hipGetLastError());
-	int rc = reduce_allreduce();
-	if (!rc) rc = step(0);
+	rc = step(0);
 	if (rc) return rc;
 	for (int i = 0; i < count; i++) {
 		if (i + 1 < count) { rc = step(i + 1); if (rc) return rc; }
-		for (bool done = false; !done;) {
-			for (int k = 0; k < 20000 && !done; k++) {
-				done = (words[4 * (i & 1) + 3] == seq[i & 1]);
-				if (!done) __builtin_ia32_pause();
-			}
-			if (!done) {
-				const hipError_t e = hipStreamQuery(c.st);
-				if (e == hipSuccess) done = true;
-				else if (e != hipErrorNotReady) HIPCHK(e);
-			}
-		}
-		if (words[4 * (i & 1)] != 0) {
-			// rejected on every rank alike (the verdict comes from the all-reduced matrix): drain -- the collectives enqueued ahead are the
-			// same on all ranks --, then this call and the rest as blocking calls with their whole ladder
-			HIPCHK(hipStreamSynchronize(c.st));
-			for (int k = i; k < count; k++) {
-				Ctx cc;
-				cc.comm = env.comm;
-				const int st = qr_dist_common(cc, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, env.nranks, stream);
-				if (st) return st;
-			}
-			return TSQR_MI_SUCCESS;
-		}
+		rc = wait_word(words + 4 * (i & 1) + 3, seq[i & 1], c.st);
+		if (rc) return rc;
+		if (words[4 * (i & 1)] != 0) return rejected_tail(env, mt, count, cl, i, words, c.st, done);
+		mt.state(i, TSQR_MI_SUCCESS);
+		*done = i + 1;
 	}
 	t_last_engine = 3;
+	prof_collect();
 	return TSQR_MI_SUCCESS;
 }
 
-static int stream_of_calls(const CallEnv& env, int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
-                           size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
-	if (!env.dist && g_set.loop_depth.load() >= 3) {
-		int st = stream_of_calls_chained(count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
-		if (st != -2) return st;
-		st = stream_of_calls_wide_chained(count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
-		if (st != -2) return st;
-	}
-	if (env.dist && g_set.loop_depth.load() >= 3 && count >= 3) {      // (conditions every rank shares; the rest is agreed on inside)
-		const int st = stream_of_calls_dist_chained(env, count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, stream);
-		if (st != -2) return st;
-	}
+// Two calls in flight: call i + 1 is submitted before call i is finished; the completion word of call i is raised by the first kernel of
+// call i + 1 (stream order: it starts when call i has finished), only the last call carries a completion kernel of its own.  Stream order
+// is the blocking order, so any operand overlap the blocking calls allow is fine here.  Row-partitioned calls: every rank takes the same
+// verdicts (they come from the all-reduced Gram matrix), hence the same path through this loop and the same order of collectives.
+static int two_in_flight(const CallEnv& env, const Mats& mt, int count, const Call& cl) {
+	auto submit = [&](int i, tsqr_mi_ticket* t, tsqr_mi_ticket* announce, bool own_flag) {
+		return submit_impl(env, cl.mode, cl.reorth, mt.q(i), cl.ldq, mt.r(i), cl.ldr, mt.a(i), cl.lda, cl.m, cl.n, cl.wq, cl.wr, cl.h_wl, cl.stream, t, announce, own_flag);
+	};
 	tsqr_mi_ticket tk[2];
-	int st = submit_impl(env, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream, &tk[0], nullptr, /*own_flag=*/count == 1);
-	if (st) return st;
+	int first = 0;
+	int st = submit(0, &tk[0], nullptr, /*own_flag=*/count == 1);
+	if (st) { for (int k = 0; k < count; k++) mt.state(k, st); return st; }           // (invalid size / mode: the same for every call of the stream)
 	for (int i = 0; i < count; i++) {
 		tsqr_mi_ticket* cur = &tk[i & 1];
 		tsqr_mi_ticket* nxt = (i + 1 < count) ? &tk[(i + 1) & 1] : nullptr;
 		if (nxt) {
-			st = submit_impl(env, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream, nxt, cur, /*own_flag=*/i + 2 == count);
+			st = submit(i + 1, nxt, cur, /*own_flag=*/i + 2 == count);
 			if (st) { (void)finish_impl(env, cur); return st; }
 		}
 		st = finish_impl(env, cur);
-		if (st) { if (nxt) (void)finish_impl(env, nxt); return st; }
+		mt.state(i, st);
+		if (st && !first) first = st;
+		if (st < 0 || (st && mt.same())) { if (nxt) (void)finish_impl(env, nxt); return st; }   // (a loop over one triple stops at its first non-zero state)
 	}
-	return TSQR_MI_SUCCESS;
+	return first;
+}
+
+// `count` calls as a stream.  Depth 3: the chained schedules as far as they go -- a rejected call ends one, the stream goes on behind it
+// with a fresh one (after a second rejection: two in flight for the rest, every attempt of a chained schedule would be thrown away).
+static int stream_of_calls(const CallEnv& env, const Mats& mt, int count, const Call& cl) {
+	const int depth = g_set.loop_depth.load();
+	int first = 0;
+	if (count < 2 || depth < 2) {
+		for (int i = 0; i < count; i++) {
+			const int st = blocking_one(env, mt, i, cl);
+			mt.state(i, st);
+			if (st && !first) first = st;
+			if (st < 0 || (st && mt.same())) return st;
+		}
+		return first;
+	}
+	int pos = 0, rejections = 0;
+	while (depth >= 3 && count - pos >= 3 && rejections < 2) {
+		const Mats sub = mt.from(pos);
+		int done = 0, st;
+		if (env.dist) st = chained_dist(env, sub, count - pos, cl, &done);
+		else {
+			st = chained64(sub, count - pos, cl, &done);
+			if (st == NOT_MINE) st = chained128(sub, count - pos, cl, &done);
+		}
+		if (st == NOT_MINE) break;
+		if (st < 0) return st;
+		if (st && !first) first = st;
+		if (pos + done < count) rejections++;
+		pos += done;
+	}
+	if (pos < count) {
+		const int st = two_in_flight(env, mt.from(pos), count - pos, cl);
+		if (st < 0) return st;
+		if (st && !first) first = st;
+	}
+	return first;
 }
 
 void tsqr_mi_set_loop_depth(int depth) { g_set.loop_depth = depth < 2 ? 1 : (depth == 2 ? 2 : 3); }
 
 // `count` calls with the same arguments: the reference's speed protocol (src/test.cu:299-309 is such a C++ loop around its call).
-// Two calls in flight (submit i + 1, then finish i) unless tsqr_mi_set_loop_depth(1).  Returns the first non-zero state.
+// Returns the first non-zero state.
 int tsqr_mi_qr_f32_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                         size_t m, size_t n, void* wq_v, void* wr_v, float* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
-	if (count < 2 || g_set.loop_depth.load() < 2) {
-		for (int i = 0; i < count; i++) {
-			const int st = tsqr_mi_qr_f32(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
-			if (st) return st;
-		}
-		return TSQR_MI_SUCCESS;
-	}
-	return stream_of_calls(CallEnv{}, count, mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
+	(void)reorth_w; (void)d_wl;
+	Mats mt;
+	mt.q0 = q; mt.r0 = r; mt.a0 = a;
+	return stream_of_calls(CallEnv{}, mt, count, Call{mode, reorth, ldq, ldr, lda, m, n, wq_v, wr_v, h_wl, stream});
+}
+
+// `count` DIFFERENT matrices of one shape (include/tsqr_mi.h): the caller of mtk::qr::qr with many matrices -- the stream of calls above
+// over one (q, r, a) triple per call.
+int tsqr_mi_qr_f32_batch(int count, int mode, int reorth, float* const* q, size_t ldq, float* const* r, size_t ldr, float* const* a, size_t lda,
+                         size_t m, size_t n, void* wq_v, void* wr_v, float* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream, int* states) {
+	(void)reorth_w; (void)d_wl;
+	if (count < 0 || (count > 0 && (!q || !r || !a))) return TSQR_MI_ERROR_INVALID_SIZE;
+	Mats mt;
+	mt.qs = q; mt.rs = r; mt.as = a; mt.states = states;
+	return stream_of_calls(CallEnv{}, mt, count, Call{mode, reorth, ldq, ldr, lda, m, n, wq_v, wr_v, h_wl, stream});
 }
 
 // ---- fp16 I/O modes: reference mtk::qr::qr<fp16_notc | fp16_tc_nocor, Reorthogonalize> (src/blockqr.cu:437-449; io and working
@@ -1795,19 +1949,22 @@ static int stream_of_calls_f16(int count, int mode, void* q, size_t ldq, void* r
                                size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
 	auto aligned16 = [](const void* p, size_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
 	const int emode = f16_engine_mode(mode);
-	if (emode < 0 || n > m || m == 0 || n == 0 || n > PW || n <= 16 || ldq < m || lda < m || ldr < n || !aligned16(a, lda) || !aligned16(q, ldq)) return -2;
+	if (emode < 0 || n > m || m == 0 || n == 0 || n > PW || n <= 16 || ldq < m || lda < m || ldr < n || !aligned16(a, lda) || !aligned16(q, ldq)) return NOT_MINE;
 	Ctx c;
 	init_ctx(c, wq_v, wr_v, m, n, stream);
 	c.rows_global = (double)m;
 	resolve_host_sig(c, h_wl, m);
-	if (!(c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug)) return -2;
+	if (!(c.policy == 0 && c.gram_level == 2 && c.hsig.dev && !t_prof.on && !g_set.debug)) return NOT_MINE;
 	float* r32 = reinterpret_cast<float*>(wq_v) + f16_tail_offset(m, n) + 2 * f16_ld(m) * n;
 	const int engine = engine_of(emode);
 	volatile unsigned* words = reinterpret_cast<volatile unsigned*>(c.hsig.host);
 	unsigned seq[2] = {0, 0};
 	// n = 64, three calls or more: the chained schedule (tsqr_mi_qr_f32_loop's, with gram_h_chain_kernel) -- the R-factor chain of call i
 	// inside the Gram launch of call i + 1, two sets of partials
-	const bool chained = (n == PW && count >= 3 && g_set.loop_depth.load() >= 3);
+	Mats mt;                                             // (the chained launch order needs Q and R of call i clear of A of call i + 1: chain_order_safe)
+	mt.q0 = reinterpret_cast<float*>(q); mt.r0 = reinterpret_cast<float*>(r); mt.a0 = const_cast<float*>(reinterpret_cast<const float*>(a));
+	const bool chained = (n == PW && count >= 3 && g_set.loop_depth.load() >= 3 &&
+	                      chain_order_safe(mt, count, Call{mode, 0, ldq, ldr, lda, m, n, wq_v, wr_v, h_wl, stream}, sizeof(_Float16)));
 	const GramPlan g = gram_plan(m, n);
 	const int nelem = 10 * 256, nred = nelem / 16;
 	double* part[2] = {reinterpret_cast<double*>(c.wr), reinterpret_cast<double*>(c.wr) + (size_t)g.nblocks * nelem};
@@ -1898,7 +2055,7 @@ int tsqr_mi_qr_f16_loop(int count, int mode, int reorth, void* q, size_t ldq, vo
                         size_t m, size_t n, void* wq_v, void* wr_v, void* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
 	if (count >= 2 && g_set.loop_depth.load() >= 2 && !reorth) {
 		const int st = stream_of_calls_f16(count, mode, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
-		if (st != -2) return st;
+		if (st != NOT_MINE) return st;
 	}
 	for (int i = 0; i < count; i++) {
 		const int st = tsqr_mi_qr_f16(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
@@ -1946,13 +2103,9 @@ int tsqr_mi_qr_f32_dist_cb(int mode, int reorth, float* q, size_t ldq, float* r,
 int tsqr_mi_qr_f32_dist_fn_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                                 size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
                                 void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream) {
-	if (count < 2 || g_set.loop_depth.load() < 2 || !nccl_comm || !nccl_allreduce_fn || !nccl_allgather_fn) {
-		for (int i = 0; i < count; i++) {
-			const int st = tsqr_mi_qr_f32_dist_fn(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, nccl_comm,
-			                                      nccl_allreduce_fn, nccl_allgather_fn, nranks, stream);
-			if (st) return st;
-		}
-		return TSQR_MI_SUCCESS;
+	if (!nccl_comm || !nccl_allreduce_fn || !nccl_allgather_fn) {
+		t_last_error = "row-partitioned call needs an ncclComm_t and the ncclAllReduce / ncclAllGather entry points of the library that created it";
+		return TSQR_MI_ERROR_UNSUPPORTED;
 	}
 	CallEnv env;
 	env.dist = true; env.nranks = nranks;
@@ -1960,23 +2113,21 @@ int tsqr_mi_qr_f32_dist_fn_loop(int count, int mode, int reorth, float* q, size_
 	env.comm.nccl_allreduce = reinterpret_cast<nccl_allreduce_t>(nccl_allreduce_fn);
 	env.comm.nccl_allgather = reinterpret_cast<nccl_allgather_t>(nccl_allgather_fn);
 	env.comm.gather_buf = gather_buf;
-	return stream_of_calls(env, count, mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, nullptr, stream);
+	Mats mt;
+	mt.q0 = q; mt.r0 = r; mt.a0 = a;
+	return stream_of_calls(env, mt, count, Call{mode, reorth, ldq, ldr, lda, m_local, n, wq_v, wr_v, nullptr, stream});
 }
 int tsqr_mi_qr_f32_dist_cb_loop(int count, int mode, int reorth, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda,
                                 size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
                                 tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream) {
-	if (count < 2 || g_set.loop_depth.load() < 2 || !allreduce || !allgather) {
-		for (int i = 0; i < count; i++) {
-			const int st = tsqr_mi_qr_f32_dist_cb(mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, gather_buf, allreduce, allgather, user, nranks, stream);
-			if (st) return st;
-		}
-		return TSQR_MI_SUCCESS;
-	}
+	if (!allreduce || !allgather) return TSQR_MI_ERROR_UNSUPPORTED;
 	CallEnv env;
 	env.dist = true; env.nranks = nranks;
 	env.comm.cb_allreduce = allreduce; env.comm.cb_allgather = allgather; env.comm.cb_user = user;
 	env.comm.gather_buf = gather_buf;
-	return stream_of_calls(env, count, mode, reorth, q, ldq, r, ldr, a, lda, m_local, n, wq_v, wr_v, nullptr, stream);
+	Mats mt;
+	mt.q0 = q; mt.r0 = r; mt.a0 = a;
+	return stream_of_calls(env, mt, count, Call{mode, reorth, ldq, ldr, lda, m_local, n, wq_v, wr_v, nullptr, stream});
 }
 
 // ---- staged entry points (building blocks; every call builds its own context) ----

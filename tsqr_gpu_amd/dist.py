@@ -280,9 +280,11 @@ class RowPartitionedQR:
     def qr(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None):
         """q, a: column-major m_local x n blocks (tensors; q may alias a only with reorthogonalize... never for the first sweep);
         r: (n, n) tensor receiving the column-major R, identical on every rank.  Blocking, collective.  Returns state_t.
-        m_local: this call's block height when it differs from the constructor's (collective check that no rank passes 0; not taller
-        than the constructor's, which sized the work buffers)."""
-        if m_local is not None and m_local != self.m_local:
+        m_local: this call's block height (not taller than the constructor's, which sized the work buffers).  Passing it is a
+        COLLECTIVE decision: when any rank passes m_local to a call, every rank must pass it to that call (its own value; the
+        constructor's is fine) -- the check that no rank holds an empty block is an all-reduce every rank has to post, whether or not
+        its own height changed."""
+        if m_local is not None:
             self._require_rows(m_local)
         m_local = self.m_local if m_local is None else m_local
         return self.backend.qr_dist(q, ldq, r, self.n, a, lda, m_local, bool(reorthogonalize))
@@ -290,8 +292,8 @@ class RowPartitionedQR:
     def bind(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None, loop=False):
         """The same call with its arguments marshalled once: returns a zero-argument callable (a C++ caller's loop body); loop = True:
         a callable taking a count k = k back-to-back calls from one C loop.  The tensors and the current stream must stay alive and
-        unchanged while it is in use."""
-        if m_local is not None and m_local != self.m_local:
+        unchanged while it is in use.  m_local: as in qr() -- passed by every rank or by none."""
+        if m_local is not None:
             self._require_rows(m_local)
         m_local = self.m_local if m_local is None else m_local
         if hasattr(self.backend, "bind_dist"):
