@@ -211,12 +211,13 @@ def spawn_own_ranks(argv, gpus):
     return subprocess.call(cmd, env=env)
 
 
-def make_input(args, m, n, m_glob, rank, dev):
+def make_input(args, m, n, m_glob, rank, dev, seed=0):
+    """seed 0: the workload's matrix; seeds 1, 2, ...: further matrices of the same kind (the rotating-buffer windows)"""
     if args.input == "uniform" or args.rehearse:
-        return synth_block(m, n, m_glob, rank * m, 0, dev)
+        return synth_block(m, n, m_glob, rank * m, seed, dev)
     # C5: latms-style A = U diag(s) V^T with the reference's singular-value draw (src/test_cond.cu:31-50), cond 1e8, fixed seed
     from tsqr_gpu_amd import harness
-    return harness.get_rand_matrix_with_cond_number(m, n, 1e8, seed=5, device=dev)
+    return harness.get_rand_matrix_with_cond_number(m, n, 1e8, seed=5 + seed, device=dev)
 
 
 def roofline_of(prof, steps, m, n, io_half, world):
@@ -292,7 +293,7 @@ def main():
     single = world == 1 and not args.force_dist and not args.rehearse
 
     def new_triple(seed):
-        a = (make_input(args, m, n, m_glob, rank, dev) if seed == 0 else synth_block(m, n, m_glob, rank * m, seed, dev)).to(io_dt)
+        a = make_input(args, m, n, m_glob, rank, dev, seed).to(io_dt)
         if args.ld_pad:
             a_pad = torch.zeros(n, ld, dtype=io_dt, device=dev)
             a_pad[:, :m] = a

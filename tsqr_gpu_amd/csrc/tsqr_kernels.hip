@@ -1185,6 +1185,69 @@ __shared__ unsigned long long chol_stamp_lds[4 * CHOL_NSTAMP];
 typedef double f64x2c __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
+// chol_section4: the owner's section of a group of four pivots K0 .. K0+3 -- the critical path of the whole step.  The wave holds, per
+// lane j, column j of the group's four rows of G (g[0..3]) and of M = R^-T (mm[0..3]).  Rounds 1-3 walked the four pivots one after
+// the other, each waiting for lane broadcasts of values the pivot before it had just produced (pivot -> rsq -> scale -> broadcast ->
+// fma -> next pivot: ~310 cycles a pivot, in-kernel stamps).  Round 4: the 4 x 4 diagonal block of the group is broadcast ONCE, up front
+// (ten lane reads, all independent), and every lane factors it privately -- a chain of four rsq + Newton steps with no cross-lane
+// traffic at all -- while the scalings and eliminations of its own column follow in the chain's shadow.  Same operations on the same
+// operands as before (the trailing matrix is exactly symmetric, so the private copy l[v][u] IS what lane K0+v computes for R[K0+u][K0+v]):
+// R, Z and the verdict are bit for bit those of rounds 1-3.
+//   out: rk[u] = R[K0+u][j], mk[u] = M[K0+u][j] (zero for rows >= n), piv0[u] = the pivot before clamping (verdict: pv[])
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chol_section4(double (&g)[4], double (&mm)[4], const int K0, const int j, const int n,
+                                              double (&rk)[4], double (&mk)[4], double (&piv0)[4]) {
+	// a[u][v] = G'[K0+u][K0+v], v <= u: register u of lane K0+v
+	double a00 = bcast_lane_f64(g[0], K0);
+	double a10 = bcast_lane_f64(g[1], K0), a11 = bcast_lane_f64(g[1], K0 + 1);
+	double a20 = bcast_lane_f64(g[2], K0), a21 = bcast_lane_f64(g[2], K0 + 1), a22 = bcast_lane_f64(g[2], K0 + 2);
+	double a30 = bcast_lane_f64(g[3], K0), a31 = bcast_lane_f64(g[3], K0 + 1), a32 = bcast_lane_f64(g[3], K0 + 2), a33 = bcast_lane_f64(g[3], K0 + 3);
+	auto inv_sqrt = [](double piv) {
+		double y = __builtin_amdgcn_rsq(piv);
+		return fma(0.5 * y, fma(-piv * y, y, 1.0), y);       // one Newton step (v_rsq_f64 is good to ~2^-23: 2^-45 after it)
+	};
+	const bool live0 = K0 < n, live1 = K0 + 1 < n, live2 = K0 + 2 < n, live3 = K0 + 3 < n;
+	// pivot 0
+	piv0[0] = a00;
+	const double p0 = (a00 > 0.0) ? a00 : 1.0;               // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
+	const double y0 = inv_sqrt(p0);
+	const double l10 = live0 ? a10 * y0 : 0.0, l20 = live0 ? a20 * y0 : 0.0, l30 = live0 ? a30 * y0 : 0.0;
+	a11 = fma(-l10, l10, a11); a21 = fma(-l20, l10, a21); a31 = fma(-l30, l10, a31);
+	a22 = fma(-l20, l20, a22); a32 = fma(-l30, l20, a32); a33 = fma(-l30, l30, a33);
+	// pivot 1
+	piv0[1] = a11;
+	const double p1 = (a11 > 0.0) ? a11 : 1.0;
+	const double y1 = inv_sqrt(p1);
+	const double l21 = live1 ? a21 * y1 : 0.0, l31 = live1 ? a31 * y1 : 0.0;
+	a22 = fma(-l21, l21, a22); a32 = fma(-l31, l21, a32); a33 = fma(-l31, l31, a33);
+	// pivot 2
+	piv0[2] = a22;
+	const double p2 = (a22 > 0.0) ? a22 : 1.0;
+	const double y2 = inv_sqrt(p2);
+	const double l32 = live2 ? a32 * y2 : 0.0;
+	a33 = fma(-l32, l32, a33);
+	// pivot 3
+	piv0[3] = a33;
+	const double p3 = (a33 > 0.0) ? a33 : 1.0;
+	const double y3 = inv_sqrt(p3);
+	// this lane's column: row K of R is g * y right of the diagonal, piv * y on it, zero left of it; row K of M is mm * y
+	rk[0] = !live0 ? 0.0 : ((j > K0) ? g[0] * y0 : ((j == K0) ? p0 * y0 : 0.0));
+	mk[0] = live0 ? mm[0] * y0 : 0.0;
+	g[1] = fma(-l10, rk[0], g[1]); mm[1] = fma(-l10, mk[0], mm[1]);
+	g[2] = fma(-l20, rk[0], g[2]); mm[2] = fma(-l20, mk[0], mm[2]);
+	g[3] = fma(-l30, rk[0], g[3]); mm[3] = fma(-l30, mk[0], mm[3]);
+	rk[1] = !live1 ? 0.0 : ((j > K0 + 1) ? g[1] * y1 : ((j == K0 + 1) ? p1 * y1 : 0.0));
+	mk[1] = live1 ? mm[1] * y1 : 0.0;
+	g[2] = fma(-l21, rk[1], g[2]); mm[2] = fma(-l21, mk[1], mm[2]);
+	g[3] = fma(-l31, rk[1], g[3]); mm[3] = fma(-l31, mk[1], mm[3]);
+	rk[2] = !live2 ? 0.0 : ((j > K0 + 2) ? g[2] * y2 : ((j == K0 + 2) ? p2 * y2 : 0.0));
+	mk[2] = live2 ? mm[2] * y2 : 0.0;
+	g[3] = fma(-l32, rk[2], g[3]); mm[3] = fma(-l32, mk[2], mm[3]);
+	rk[3] = !live3 ? 0.0 : ((j > K0 + 3) ? g[3] * y3 : ((j == K0 + 3) ? p3 * y3 : 0.0));
+	mk[3] = live3 ? mm[3] * y3 : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // chol_body16: the step on SIXTEEN waves -- thread (w = wave, j = lane) holds column j of the four rows 4w .. 4w+3 of G and of
 // M = R^-T, i.e. wave w owns exactly one "group" of four pivots.  The owner factors its four rows against each other in registers
 // (lane broadcasts, no LDS: v_rsq_f64 + one Newton step per pivot), publishes the four finished rows in LDS (double buffered), and
@@ -1269,12 +1332,19 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 		}
 		__syncthreads();
 	}
-	double g[4], mm[4];
+	// Round 4: the rows are PACKED.  Of row i = 4w + u the elimination only ever needs G[i][j] for j >= 4w (upper triangle + the wave's
+	// own 4 x 4 diagonal block) and M[i][j] for j < 4w (M = R^-T is lower triangular, and its own diagonal block is touched by nothing
+	// but the owner's section): lane j of x[u] holds G[i][j] for j >= 4w and M[i][j] for j < 4w, md[u] the diagonal block of M (identity
+	// until the section).  A rank-4 update is then 16 fp64 FMAs per wave instead of 32 -- the step is bound by the fp64 issue of the four
+	// SIMDs of its one CU (stamps: a group cost ~2000 cycles = four waves x 32 FMAs x ~10 cycles + the owner's section per SIMD).  Every
+	// element sees the same operations in the same order as before: R, Z and the verdict are unchanged bit for bit.
+	const bool gpart = j >= 4 * w;
+	double x[4], md[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
 		const int i = 4 * w + u;
-		g[u] = Gs[i * 65 + j];
-		mm[u] = (i == j) ? 1.0 : 0.0;
+		x[u] = gpart ? Gs[i * 65 + j] : 0.0;
+		md[u] = (i == j) ? 1.0 : 0.0;
 	}
 	if (t < 64) { dg[t] = Gs[t * 65 + t]; pv[t] = 1.0; }
 	const double dgj = Gs[j * 65 + j];
@@ -1283,33 +1353,27 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 	CHOL_STAMP16(1);
 	const int ngroups = (n + 3) >> 2;
 	// owner section of group gi: the four pivots, rows factored against each other in registers (lane broadcasts), published
-	auto section = [&](int gi) {
+	auto section = [&](int gi) __attribute__((always_inline)) {      // (called from two places: left out of line, x / md would live in scratch memory)
 		const int K0 = 4 * gi;
 		double* rr = Rrow + (gi & 1) * 256;              // [4][64]
 		double* mr = Mrow + (gi & 1) * 256;
-		static_for<0, 4>([&](auto uu) {
-			constexpr int u = decltype(uu)::value;
-			const int K = K0 + u;
-			const double piv0 = bcast_lane_f64(g[u], K);
-			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
-			double y = __builtin_amdgcn_rsq(piv);
-			y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);      // one Newton step
-			const bool live = K < n;
-			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
-			const double mk = live ? mm[u] * y : 0.0;
-			static_for<u + 1, 4>([&](auto vv) {
-				constexpr int v = decltype(vv)::value;
-				const double rkv = bcast_lane_f64(rk, K0 + v);   // R[K][K0+v]
-				g[v] = fma(-rkv, rk, g[v]);
-				mm[v] = fma(-rkv, mk, mm[v]);
-			});
-			rr[u * 64 + j] = rk;
-			mr[u * 64 + j] = mk;
-			if (j == 0 && live) pv[K] = piv0;
-		});
+		double g[4], mm[4], rk[4], mk[4], piv0[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {                    // (K0 = 4w: the G lanes are j >= K0, where the section reads them)
+			const double xv = x[u], mv = md[u];              // (values first, then the select: a select between the two ADDRESSES puts the arrays in scratch memory)
+			g[u] = xv;
+			mm[u] = gpart ? mv : xv;
+		}
+		chol_section4(g, mm, K0, j, n, rk, mk, piv0);
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			rr[u * 64 + j] = rk[u];
+			mr[u * 64 + j] = mk[u];
+			if (j == 0 && K0 + u < n) pv[K0 + u] = piv0[u];
+		}
 	};
 	// rank-4 update of this wave's four rows with the published rows of group gi: R part first (an owner's pivots wait for it), then M
-	auto update = [&](int gi) {
+	auto update = [&](int gi) __attribute__((always_inline)) {
 		const double* rr = Rrow + (gi & 1) * 256;
 		const double* mr = Mrow + (gi & 1) * 256;
 		double rki[4][4], rkj[4], mkc[4];
@@ -1321,14 +1385,16 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 			rkj[u] = rr[u * 64 + j];
 			mkc[u] = mr[u * 64 + j];
 		}
+		double yv[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {                    // G lanes take row K of R, M lanes row K of M
+			const double rv = rkj[u], mv = mkc[u];
+			yv[u] = gpart ? rv : mv;
+		}
 #pragma unroll
 		for (int sl = 0; sl < 4; sl++)
 #pragma unroll
-			for (int u = 0; u < 4; u++) g[sl] = fma(-rki[u][sl], rkj[u], g[sl]);
-#pragma unroll
-		for (int sl = 0; sl < 4; sl++)
-#pragma unroll
-			for (int u = 0; u < 4; u++) mm[sl] = fma(-rki[u][sl], mkc[u], mm[sl]);
+			for (int u = 0; u < 4; u++) x[sl] = fma(-rki[u][sl], yv[u], x[sl]);
 	};
 	if (w == 0) section(0);
 #pragma unroll 1
@@ -1338,7 +1404,8 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 		CHOL_STAMP16(8 + 8 * gi + 2);
 		if (w == gi + 1 && gi + 1 < ngroups) {
 			// the next owner: update and owner section as ONE block of straight-line code -- the update of its rows of M has no
-			// part in the pivot chain and fills the chain's latency gaps instead of standing in front of it
+			// part in the pivot chain and fills the chain's latency gaps instead of standing in front of it.  (Round 4: raising this
+			// wave's issue priority with s_setprio for the length of the block changed nothing: 15.9 vs 15.7 us.)
 			update(gi);
 			section(gi + 1);
 		} else if (w > gi) {
@@ -1415,6 +1482,14 @@ struct CholArgs {
 	int level;                           // 2 bf16-split Gram matrix (f32 accumulator layout; pivot ratio > 2^-5, S bound, column norms >= 2^-90 rows),
 	                                     // 1 fp64 Gram matrix (f64 accumulator layout; ratio > 2^-40), 3 shifted fp64 (ratio > 0: rejects only non-finite input)
 	float scond_floor;                   // bf16 level: S <= min(128, max(scond_floor, 0.12 sqrt(rows)))
+	int relax;                           // level 2 only: 1 = ANOTHER SWEEP FOLLOWS on the Q this factor produces (reorthogonalised calls), so Q need
+	                                     // only come out well conditioned, not orthonormal: pivot ratio > 2^-20, S <= min(4e6, 2500 sqrt(rows))
+	                                     // (loss of orthogonality of this sweep ~8e-6 S / sqrt(rows) <= 0.02: the next sweep sees cond(Q) ~ 1)
+	int retry_shift;                     // level 2 only, 1: a matrix the (relaxed) rule rejects is factored again at once, in the same launch, as
+	                                     // G + s I, s = c trace(G), c = max(11 (rows n + n (n + 1)) 2^-53, 8 n 2^-23 / sqrt(rows)) -- shifted Cholesky QR
+	                                     // on the bf16-split Gram matrix (qr_core); `rows` is the all-reduced count of a row-partitioned call, so every
+	                                     // rank applies the same shift.  status[3] = 1 and host word 0 = 2 tell "shifted": two more sweeps must follow.
+	                                     // The host words are written once, at the end of the launch.
 };
 
 // the 64-column path's launch of the step.  prev_status: status word of an earlier factorisation this one depends on (speculatively
@@ -1434,13 +1509,36 @@ __global__ __launch_bounds__(1024) void chol16_kernel(const CholArgs a) {
 		min_ratio = 0.03125f;
 		max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
 		min_diag = rows * 0x1p-90;
+		if (a.relax) { min_ratio = 0x1p-20f; max_scond = fminf(4.0e6f, 2500.0f * sqrtf((float)rows)); }
 	} else if (a.level == 1) {
 		min_ratio = 9.094947017729282e-13f;              // 2^-40
 	} else {
 		shift = a.shift_coef * (rows * (double)a.n + (double)a.n * (double)(a.n + 1));
 	}
-	chol_body16(a.r, a.ldr, a.z, a.status, a.host_status, [&](int e) { return a.gsum[e]; }, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond,
-	            shift, min_diag);
+	const bool retry = a.level == 2 && a.retry_shift != 0;
+	auto loadg = [&](int e) { return a.gsum[e]; };
+	chol_body16(a.r, a.ldr, a.z, a.status, retry ? nullptr : a.host_status, loadg, a.n, a.NT, a.level == 2 ? 1 : 0, min_ratio, max_scond, shift, min_diag);
+	if (!retry) return;
+	// (thread 0 wrote the verdict itself: program order)
+	__shared__ unsigned again;
+	__syncthreads();
+	if (threadIdx.x == 0) { again = a.status[0]; a.status[3] = 0u; }
+	__syncthreads();
+	if (again) {
+		// rejected: the same Gram matrix, shifted.  Accepted whenever every pivot is positive (non-finite input stays rejected); the
+		// column-norm floor of the bf16-split level still holds (products near the denormal range were not accumulated accurately)
+		const double nn = (double)a.n;
+		const double coef = fmax(11.0 * (rows * nn + nn * (nn + 1.0)) * 0x1p-53, 8.0 * nn * 0x1p-23 / sqrt(rows));
+		chol_body16(a.r, a.ldr, a.z, a.status, nullptr, loadg, a.n, a.NT, 1, 0.0f, INFINITY, coef, min_diag);
+		__syncthreads();
+		if (threadIdx.x == 0 && a.status[0] == 0u) a.status[3] = 1u;
+	}
+	if (threadIdx.x == 0 && a.host_status) {
+		volatile unsigned* hs = a.host_status;
+		hs[1] = a.status[1];
+		hs[2] = a.status[2];
+		hs[0] = (a.status[0] == 0u && a.status[3] != 0u) ? 2u : a.status[0];
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1462,28 +1560,18 @@ __device__ __forceinline__ void chol_group4(double (&g)[16], double (&mm)[16], d
 	double* mr = Mrow + (U & 1) * 256;
 	if (w == U) {
 		// the owner's section is the critical path (three waves wait at the barrier): nothing but the pivots, the two row
-		// scalings, the in-group eliminations and the publication of the rows; fp32 copies, Z and the verdict sums are taken
-		// from the published rows by a wave that is off the path (below)
-		static_for<0, 4>([&](auto uu) {
-			constexpr int u = decltype(uu)::value;
-			const int K = K0 + u;
-			const double piv0 = bcast_lane_f64(g[u], K);
-			const double piv = (piv0 > 0.0) ? piv0 : 1.0;    // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
-			double y = __builtin_amdgcn_rsq(piv);
-			y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);      // one Newton step (v_rsq_f64 is good to ~2^-23: 2^-45 after it)
-			const bool live = K < n;
-			const double rk = !live ? 0.0 : ((j > K) ? g[u] * y : ((j == K) ? piv * y : 0.0));
-			const double mk = live ? mm[u] * y : 0.0;
-			static_for<u + 1, 4>([&](auto vv) {
-				constexpr int v = decltype(vv)::value;
-				const double rkv = bcast_lane_f64(rk, K0 + v);   // R[K][K0+v]
-				g[v] = fma(-rkv, rk, g[v]);
-				mm[v] = fma(-rkv, mk, mm[v]);
-			});
-			rr[u * 64 + j] = rk;
-			mr[u * 64 + j] = mk;
-			if (j == 0 && live) pv[K] = piv0;
-		});
+		// scalings, the in-group eliminations and the publication of the rows (chol_section4); fp32 copies, Z and the verdict sums
+		// are taken from the published rows by a wave that is off the path (below)
+		double g4[4] = {g[0], g[1], g[2], g[3]}, m4[4] = {mm[0], mm[1], mm[2], mm[3]};
+		double rk[4], mk[4], piv0[4];
+		chol_section4(g4, m4, K0, j, n, rk, mk, piv0);
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			g[u] = g4[u]; mm[u] = m4[u];
+			rr[u * 64 + j] = rk[u];
+			mr[u * 64 + j] = mk[u];
+			if (j == 0 && K0 + u < n) pv[K0 + u] = piv0[u];
+		}
 	}
 	lds_barrier();                                       // (LDS only: the result stores below stay in flight across the groups)
 	double rkj[4], mkc[4];

@@ -50,6 +50,11 @@ struct Settings {
 	// the two environment switches that are left (read once at load): the floor of the bf16-split level's bound on the scaled
 	// conditioning S, and a diagnostic print of every Cholesky verdict
 	const float bf16_scond_floor = (float)env_int("TSQR_MI_BF16_MAX_SCOND", 4);
+	// chained schedules over DIFFERENT matrices: taken when one matrix is at most this many MiB.  The Gram pass of matrix i + 1 runs
+	// between the Gram pass and the apply pass of matrix i; both fit the 256 MiB Infinity Cache only up to ~half of it each -- beyond
+	// that the apply pass of matrix i finds its A evicted and streams it from HBM again (measured at 2^20 x 64, 256 MiB a matrix:
+	// 0.181 ms per call chained against 0.163 in stream order, profiles/r04_experiment_log.md).  A loop over ONE matrix is not affected.
+	const int chain_max_mib = env_int("TSQR_MI_CHAIN_MAX_MIB", 112);
 	const int debug = env_int("TSQR_MI_DEBUG", 0);
 };
 Settings g_set;
@@ -183,9 +188,9 @@ constexpr int WIDE_MAX_WGS = 255;                       // gram_wide_kernel: one
                                                         // be those of the blocking call
 inline size_t wide_part_floats(size_t m) { return (std::min<size_t>((m + 63) / 64, WIDE_MAX_WGS) + 1) * 36 * 256 * 2; }
 
-// layout of wq (floats): [stack_b][Z: 4096][S: 4096][R1 copy: n*n][R2: n*n][r3, r4: 4096 each][summed tiles + row count][status]
+// layout of wq (floats): [stack_b][Z: 4096][S: 4096][R1 copy: n*n][R2: n*n][r3, r4, r5, r6: 4096 each][summed tiles + row count][status]
 constexpr size_t GSUM_DOUBLES = 16 * 256 + 8;          // 16 tiles (coupling) or 10 (Gram) + the row-count word of a row-partitioned run
-struct WqLayout { size_t z, s, r1, r2, r3, r4, gsum, status, wide, total; };
+struct WqLayout { size_t z, s, r1, r2, r3, r4, r5, r6, gsum, status, wide, total; };
 WqLayout wq_layout(size_t m, size_t n) {
 	const Plan p = make_plan(m, n);
 	WqLayout L{};
@@ -197,6 +202,8 @@ WqLayout wq_layout(size_t m, size_t n) {
 	L.r2 = o; o += n * n;
 	L.r3 = o; o += 4096;                                 // panel-local R1, R2 of the shifted-Cholesky two-step (<= 64 x 64 each)
 	L.r4 = o; o += 4096;
+	L.r5 = o; o += 4096;                                 // third sweep's factor and R2 R1 of the shifted CholeskyQR3 of a reorthogonalised call (qr_core)
+	L.r6 = o; o += 4096;
 	o = (o + 63) & ~(size_t)63;
 	L.gsum = o; o += 2 * GSUM_DOUBLES;
 	L.status = o; o += 64;
@@ -264,6 +271,8 @@ struct Ctx {
 	int start_level = -1;                                // tsqr_mi_qr_f32_finish: the ladder resumes at this level (the ones above were rejected)
 	unsigned* announce_word = nullptr;                   // completion word of the call in front of this one, raised by this call's first
 	unsigned announce_seq = 0;                           // Gram kernel (consumed by the launch that carries it)
+	int chol_relax = 0;                                  // the next bf16-level Cholesky launches use the relaxed rule (CholArgs::relax: another sweep follows)
+	int chol_retry_shift = 0;                            // ... and factor a rejected matrix again at once, shifted (CholArgs::retry_shift)
 	double rows_global = 0.0;                            // host's view of the global row count (the device thresholds of a row-partitioned
 	                                                     // call use the all-reduced count instead)
 	unsigned* status_dev(int s) const { return reinterpret_cast<unsigned*>(wq + L.status) + 16 * s; }
@@ -567,6 +576,7 @@ int chol_from_g(Ctx& c, float* r, size_t ldr, size_t n, int level) {
 	a.rows = c.rows_global;
 	a.shift_coef = (level == 3) ? 11.0 * 1.1102230246251565e-16 : 0.0;
 	a.n = (int)n; a.NT = NT; a.level = level; a.scond_floor = g_set.bf16_scond_floor;
+	if (level == 2) { a.relax = c.chol_relax; a.retry_shift = c.chol_retry_shift; }
 	{
 		ProfScope ps(KC_CHOL, c.st);
 		hipLaunchKernelGGL(tsqrmi::chol16_kernel, dim3(1), dim3(1024), 0, c.st, a);
@@ -1022,7 +1032,111 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 			// single panel: the first sweep's (last) apply launch accumulates Q^T Q while the block is in LDS, so that the second
 			// sweep's bf16-level Gram pass over Q is not needed
 			const bool fuse = n <= PW && c.policy == 0 && level == 2;
-			if (n <= PW && c.policy == 0 && level == first_level && !t_prof.on) {
+			if (n <= PW && c.policy == 0 && level == first_level && level == 2 && !t_prof.on && c.hsig.dev) {
+				// Round 4: CholeskyQR2 / shifted CholeskyQR3 on the bf16-split Gram matrix, decided on the device, no pass wasted.
+				//  sweep 1  Gram pass of A -> Cholesky under the RELAXED rule (another sweep follows: Q1 must come out well conditioned, not
+				//           orthonormal) -- and when even that rule rejects, the same launch factors G + s I at once (shifted Cholesky QR,
+				//           Fukaya et al. 2020).  s = c trace(G), c = max(11 (m n + n (n + 1)) 2^-53, 8 n 2^-23 / sqrt(m)): the first term is the
+				//           fp64 shift of the old ladder, the second covers the bf16-split Gram matrix's own entry-wise error (products good to
+				//           2^-23, averaging over the rows), so the fp64 Gram pass of A (108 us) and its rejected Cholesky are not needed.
+				//           -> Q1 = A inverse(R1), Gram tiles of Q1 from the same launch.  (Plain stores for Q1 were measured again: no hit gain
+				//           for the sweep behind it, and A is displaced from the Infinity Cache -- profiles/r03_experiment_log.md, r04.)
+				//  The host reads sweep 1's verdict word WHILE the apply pass of sweep 1 runs, then enqueues
+				//  accepted plain   : sweep 2 under the strict rule -> Q, R = R2 R1 (CholeskyQR2: what rounds 1-3 did for such input);
+				//  accepted shifted : sweep 2 under the relaxed rule (cond(Q1) ~ 1 / sqrt(c): 1e3 .. 4e3) with Gram tiles of Q2 from its
+				//                     apply launch, sweep 3 under the strict rule -> Q, R = R3 R2 R1 (shifted CholeskyQR3);
+				//  rejected         : (non-finite input, or columns near the fp32 denormal range) the checked ladder below, from scratch.
+				// Every launch behind a rejected Cholesky skips itself; A is never written.
+				constexpr unsigned PENDING = 0xffffffffu;
+				volatile unsigned* hw = reinterpret_cast<volatile unsigned*>(c.hsig.host);
+				float* r3 = c.wq + L.r5; float* r4 = c.wq + L.r6;    // (L.r3 / L.r4 belong to panel_qr's own shifted two-step)
+				c.gramq_part = reinterpret_cast<double*>(c.wr); c.gramq_cap = gram_plan(m, n).nblocks; c.gramq_nparts = 0;
+				c.slot = 0; c.prev_slot = -1;
+				hw[0] = PENDING;
+				c.chol_relax = 1; c.chol_retry_shift = 1;
+				rc = sweep(c, engine, 2, /*check_now=*/false, q, ldq, r1, n, a, lda, m, n);
+				c.chol_relax = 0; c.chol_retry_shift = 0;
+				const bool have_gramq = c.gramq_nparts > 0;
+				if (rc) { c.gramq_part = nullptr; c.gramq_cap = 0; return rc; }
+				unsigned v0 = PENDING;
+				for (;;) {                                       // sweep 1's verdict (its apply pass is running meanwhile)
+					for (int i = 0; i < 20000 && v0 == PENDING; i++) { v0 = hw[0]; if (v0 == PENDING) __builtin_ia32_pause(); }
+					if (v0 != PENDING) break;
+					const hipError_t e = hipStreamQuery(c.st);
+					if (e == hipSuccess) { v0 = hw[0]; if (v0 == PENDING) v0 = 1u; break; }
+					if (e != hipErrorNotReady) { c.gramq_part = nullptr; c.gramq_cap = 0; HIPCHK(e); }
+				}
+				unsigned s1 = 1u, s2 = 1u;
+				if (v0 == 0u) {
+					c.gramq_part = nullptr; c.gramq_cap = 0;
+					c.gramq_ready = have_gramq;
+					c.slot = 1; c.prev_slot = 0;
+					rc = sweep(c, engine, 2, /*check_now=*/false, q, ldq, r2, n, q, ldq, m, n);
+					c.gramq_ready = false;
+					c.slot = 0; c.prev_slot = -1;
+					if (rc) return rc;
+					launch_rmul(r, ldr, r2, n, r1, n, n, c.st);
+					HIPCHK(hipGetLastError());
+					rc = read_status(c, 1, &s1);
+					if (rc) return rc;
+					if (s1 == 0) break;                          // both sweeps accepted: done (min_level was set by panel_qr)
+					// the first sweep stands (Q holds Q1, r1 is valid); only the second one must be redone, checked, one level down
+					c.min_level = 2;
+					rc = sweep(c, engine, 1, /*check_now=*/true, q, ldq, r2, n, q, ldq, m, n);
+					if (rc) return rc;
+					c.min_level = std::min(c.min_level, 2);
+					launch_rmul(r, ldr, r2, n, r1, n, n, c.st);
+					HIPCHK(hipGetLastError());
+					rc = wait_done(c);
+					if (rc) return rc;
+					break;
+				}
+				if (v0 == 2u) {
+					// shifted: cond(Q1) ~ sqrt(c n / 3) cond(A), up to ~1e5 -- beyond what the bf16-split Gram matrix of Q1 resolves, so sweep 2
+					// takes the fp64 Gram matrix of Q1 (exact products)
+					c.slot = 1; c.prev_slot = 0;
+					rc = sweep(c, engine, 1, /*check_now=*/false, q, ldq, r2, n, q, ldq, m, n);
+					c.gramq_part = nullptr; c.gramq_cap = 0;
+					if (!rc) {
+						c.gramq_ready = have_gramq;              // (the same apply variant ran: fused for every engine but the fp32-MFMA one)
+						c.slot = 0; c.prev_slot = 1;             // (slot 0's first verdict has been read: its words serve the third sweep)
+						rc = sweep(c, engine, 2, /*check_now=*/false, q, ldq, r3, n, q, ldq, m, n);
+						c.gramq_ready = false;
+					}
+					c.slot = 0; c.prev_slot = -1;
+					if (rc) return rc;
+					launch_rmul(r4, n, r2, n, r1, n, n, c.st);
+					launch_rmul(r, ldr, r3, n, r4, n, n, c.st);
+					HIPCHK(hipGetLastError());
+					rc = read_status(c, 0, &s2);
+					if (rc) return rc;
+					rc = read_status(c, 1, &s1, nullptr, /*wait=*/false);
+					if (rc) return rc;
+					if (!(s1 == 0 && s2 == 0)) {
+						// Q1 is numerically rank deficient (e.g. exactly dependent columns), or sweep 3 found Q2 short of the strict rule.
+						// Q holds Q1 (sweep 2 rejected: its apply pass skipped itself) or Q2 -- A may be gone (q may alias a), so the rest is
+						// done on Q in place by checked sweeps, which escalate per panel (fp64 Gram -> shifted -> Householder)
+						if (s1 != 0) {
+							rc = sweep(c, engine, 1, /*check_now=*/true, q, ldq, r2, n, q, ldq, m, n);
+							if (rc) return rc;
+						}
+						rc = sweep(c, engine, 2, /*check_now=*/true, q, ldq, r3, n, q, ldq, m, n);
+						if (rc) return rc;
+						launch_rmul(r4, n, r2, n, r1, n, n, c.st);
+						launch_rmul(r, ldr, r3, n, r4, n, n, c.st);
+						HIPCHK(hipGetLastError());
+						rc = wait_done(c);
+						if (rc) return rc;
+					}
+					c.min_level = 0; c.used_shift = true;
+					break;
+				}
+				c.gramq_part = nullptr; c.gramq_cap = 0;
+				rc = wait_done(c);                               // rejected (non-finite input, columns near the denormal range): everything enqueued skipped itself
+				if (rc) return rc;
+				c.min_level = 2;
+				level = 1;                                       // the checked ladder, from the fp64 Gram level, on the untouched A
+			} else if (n <= PW && c.policy == 0 && level == first_level && !t_prof.on) {
 				// Optimistic attempt: both sweeps, the R product and the completion flag are enqueued without looking at a verdict.
 				// Device-side chain: apply 1 skips when Cholesky 1 rejected; Cholesky 2 then reports "rejected" at once; apply 2 (in
 				// place) skips when Cholesky 2 rejected -- so A stays intact and Q holds Q1 or garbage, never a half-applied state.
@@ -1367,6 +1481,11 @@ static bool chain_order_safe(const Mats& mt, int count, const Call& cl, size_t e
 	return true;
 }
 
+// A batch of different matrices takes a chained schedule only while two matrices share the Infinity Cache (Settings::chain_max_mib)
+static bool chain_fits_cache(const Mats& mt, const Call& cl) {
+	return mt.same() || (double)cl.lda * (double)cl.n * sizeof(float) <= (double)g_set.chain_max_mib * 1048576.0;
+}
+
 // spin on a completion word of the pinned words (the stream is looked at now and then so that a failed launch cannot hang the caller)
 static int wait_word(volatile unsigned* word, unsigned seq, hipStream_t st) {
 	for (;;) {
@@ -1440,7 +1559,7 @@ static int chained64(const Mats& mt, int count, const Call& cl, int* done) {
 		return NOT_MINE;
 	for (int i = 0; i < (mt.same() ? 1 : count); i++)
 		if ((reinterpret_cast<uintptr_t>(mt.a(i)) & 15) != 0) return NOT_MINE;
-	if (!chain_order_safe(mt, count, cl)) return NOT_MINE;
+	if (!chain_order_safe(mt, count, cl) || !chain_fits_cache(mt, cl)) return NOT_MINE;
 	Ctx c;
 	init_ctx(c, cl.wq, cl.wr, m, n, cl.stream);
 	c.rows_global = (double)m;
@@ -1543,7 +1662,7 @@ static int chained128(const Mats& mt, int count, const Call& cl, int* done) {
 		return NOT_MINE;
 	for (int i = 0; i < (mt.same() ? 1 : count); i++)
 		if ((reinterpret_cast<uintptr_t>(mt.a(i)) & 15) != 0) return NOT_MINE;
-	if (!chain_order_safe(mt, count, cl)) return NOT_MINE;
+	if (!chain_order_safe(mt, count, cl) || !chain_fits_cache(mt, cl)) return NOT_MINE;
 	Ctx c;
 	init_ctx(c, cl.wq, cl.wr, m, n, cl.stream);
 	c.rows_global = (double)m;
