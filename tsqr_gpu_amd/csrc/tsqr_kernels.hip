@@ -1483,10 +1483,10 @@ struct CholArgs {
 	                                     // 1 fp64 Gram matrix (f64 accumulator layout; ratio > 2^-40), 3 shifted fp64 (ratio > 0: rejects only non-finite input)
 	float scond_floor;                   // bf16 level: S <= min(128, max(scond_floor, 0.12 sqrt(rows)))
 	int relax;                           // level 2 only: 1 = ANOTHER SWEEP FOLLOWS on the Q this factor produces (reorthogonalised calls), so Q need
-	                                     // only come out well conditioned, not orthonormal: pivot ratio > 2^-20, S <= min(4e6, 2500 sqrt(rows))
-	                                     // (loss of orthogonality of this sweep ~8e-6 S / sqrt(rows) <= 0.02: the next sweep sees cond(Q) ~ 1)
+	                                     // only come out well conditioned, not orthonormal: pivot ratio > 2^-20, S <= min(1.6e7, 8000 sqrt(rows))
+	                                     // (loss of orthogonality of this sweep ~8e-6 S / sqrt(rows) <= 0.06: the next sweep sees cond(Q) ~ 1)
 	int retry_shift;                     // level 2 only, 1: a matrix the (relaxed) rule rejects is factored again at once, in the same launch, as
-	                                     // G + s I, s = c trace(G), c = max(11 (rows n + n (n + 1)) 2^-53, 8 n 2^-23 / sqrt(rows)) -- shifted Cholesky QR
+	                                     // G + s I, s = c trace(G), c = 8 * 2^-23 / sqrt(rows) -- shifted Cholesky QR
 	                                     // on the bf16-split Gram matrix (qr_core); `rows` is the all-reduced count of a row-partitioned call, so every
 	                                     // rank applies the same shift.  status[3] = 1 and host word 0 = 2 tell "shifted": two more sweeps must follow.
 	                                     // The host words are written once, at the end of the launch.
@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(1024) void chol16_kernel(const CholArgs a) {
 		min_ratio = 0.03125f;
 		max_scond = fminf(128.0f, fmaxf(a.scond_floor, 0.12f * sqrtf((float)rows)));
 		min_diag = rows * 0x1p-90;
-		if (a.relax) { min_ratio = 0x1p-20f; max_scond = fminf(4.0e6f, 2500.0f * sqrtf((float)rows)); }
+		if (a.relax) { min_ratio = 0x1p-20f; max_scond = fminf(1.6e7f, 8000.0f * sqrtf((float)rows)); }
 	} else if (a.level == 1) {
 		min_ratio = 9.094947017729282e-13f;              // 2^-40
 	} else {
@@ -1527,8 +1527,7 @@ __global__ __launch_bounds__(1024) void chol16_kernel(const CholArgs a) {
 	if (again) {
 		// rejected: the same Gram matrix, shifted.  Accepted whenever every pivot is positive (non-finite input stays rejected); the
 		// column-norm floor of the bf16-split level still holds (products near the denormal range were not accumulated accurately)
-		const double nn = (double)a.n;
-		const double coef = fmax(11.0 * (rows * nn + nn * (nn + 1.0)) * 0x1p-53, 8.0 * nn * 0x1p-23 / sqrt(rows));
+		const double coef = 8.0 * 0x1p-23 / sqrt(fmax(rows, 1.0));
 		chol_body16(a.r, a.ldr, a.z, a.status, nullptr, loadg, a.n, a.NT, 1, 0.0f, INFINITY, coef, min_diag);
 		__syncthreads();
 		if (threadIdx.x == 0 && a.status[0] == 0u) a.status[3] = 1u;

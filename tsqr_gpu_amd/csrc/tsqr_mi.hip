@@ -1036,9 +1036,9 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 				// Round 4: CholeskyQR2 / shifted CholeskyQR3 on the bf16-split Gram matrix, decided on the device, no pass wasted.
 				//  sweep 1  Gram pass of A -> Cholesky under the RELAXED rule (another sweep follows: Q1 must come out well conditioned, not
 				//           orthonormal) -- and when even that rule rejects, the same launch factors G + s I at once (shifted Cholesky QR,
-				//           Fukaya et al. 2020).  s = c trace(G), c = max(11 (m n + n (n + 1)) 2^-53, 8 n 2^-23 / sqrt(m)): the first term is the
-				//           fp64 shift of the old ladder, the second covers the bf16-split Gram matrix's own entry-wise error (products good to
-				//           2^-23, averaging over the rows), so the fp64 Gram pass of A (108 us) and its rejected Cholesky are not needed.
+				//           Fukaya et al. 2020).  s = c trace(G), c = 8 * 2^-23 / sqrt(rows): four times the Frobenius bound of the bf16-split Gram
+				//           matrix's own error (products good to 2^-23, errors averaging over the rows: |dG_ij| ~ 2^-22 / sqrt(rows) sqrt(g_ii g_jj),
+				//           measured as 8e-6 S / sqrt(rows) in Q^T Q), so the fp64 Gram pass of A (108 us) and its rejected Cholesky are not needed.
 				//           -> Q1 = A inverse(R1), Gram tiles of Q1 from the same launch.  (Plain stores for Q1 were measured again: no hit gain
 				//           for the sweep behind it, and A is displaced from the Infinity Cache -- profiles/r03_experiment_log.md, r04.)
 				//  The host reads sweep 1's verdict word WHILE the apply pass of sweep 1 runs, then enqueues
@@ -1092,27 +1092,39 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 					break;
 				}
 				if (v0 == 2u) {
-					// shifted: cond(Q1) ~ sqrt(c n / 3) cond(A), up to ~1e5 -- beyond what the bf16-split Gram matrix of Q1 resolves, so sweep 2
-					// takes the fp64 Gram matrix of Q1 (exact products)
-					c.slot = 1; c.prev_slot = 0;
-					rc = sweep(c, engine, 1, /*check_now=*/false, q, ldq, r2, n, q, ldq, m, n);
-					c.gramq_part = nullptr; c.gramq_cap = 0;
-					if (!rc) {
-						c.gramq_ready = have_gramq;              // (the same apply variant ran: fused for every engine but the fp32-MFMA one)
-						c.slot = 0; c.prev_slot = 1;             // (slot 0's first verdict has been read: its words serve the third sweep)
-						rc = sweep(c, engine, 2, /*check_now=*/false, q, ldq, r3, n, q, ldq, m, n);
-						c.gramq_ready = false;
+					// shifted: cond(Q1) ~ sqrt(c n / 3) cond(A).  Sweep 2 first tries the bf16-split Gram matrix of Q1 -- free, its tiles came out
+					// of sweep 1's apply launch -- under the relaxed rule (large row counts: c is small enough for cond(A) up to ~1e8); when
+					// that is rejected (Q still holds Q1: the apply pass skipped itself) it takes the fp64 Gram matrix of Q1 in a pass of its
+					// own.  Sweeps 2 and 3 are enqueued together, speculatively; sweep 3 (strict rule) reuses slot 0, whose first verdict
+					// has been read.
+					bool done3 = false;
+					for (int att = have_gramq ? 0 : 1; att < 2; att++) {
+						c.gramq_part = reinterpret_cast<double*>(c.wr); c.gramq_cap = gram_plan(m, n).nblocks;
+						c.gramq_ready = (att == 0);
+						c.slot = 1; c.prev_slot = -1;            // (sweep 1 is known to be accepted)
+						c.chol_relax = 1;
+						rc = sweep(c, engine, att == 0 ? 2 : 1, /*check_now=*/false, q, ldq, r2, n, q, ldq, m, n);
+						c.chol_relax = 0; c.gramq_ready = false;
+						c.gramq_part = nullptr; c.gramq_cap = 0;
+						if (!rc) {
+							c.gramq_ready = have_gramq;          // (the same apply variant ran: fused for every engine but the fp32-MFMA one)
+							c.slot = 0; c.prev_slot = 1;
+							rc = sweep(c, engine, 2, /*check_now=*/false, q, ldq, r3, n, q, ldq, m, n);
+							c.gramq_ready = false;
+						}
+						c.slot = 0; c.prev_slot = -1;
+						if (rc) return rc;
+						launch_rmul(r4, n, r2, n, r1, n, n, c.st);
+						launch_rmul(r, ldr, r3, n, r4, n, n, c.st);
+						HIPCHK(hipGetLastError());
+						rc = read_status(c, 0, &s2);
+						if (rc) return rc;
+						rc = read_status(c, 1, &s1, nullptr, /*wait=*/false);
+						if (rc) return rc;
+						if (s1 == 0 && s2 == 0) { done3 = true; break; }
+						if (s1 == 0) break;                      // sweep 3 alone was rejected: Q holds Q2 (checked sweep below)
 					}
-					c.slot = 0; c.prev_slot = -1;
-					if (rc) return rc;
-					launch_rmul(r4, n, r2, n, r1, n, n, c.st);
-					launch_rmul(r, ldr, r3, n, r4, n, n, c.st);
-					HIPCHK(hipGetLastError());
-					rc = read_status(c, 0, &s2);
-					if (rc) return rc;
-					rc = read_status(c, 1, &s1, nullptr, /*wait=*/false);
-					if (rc) return rc;
-					if (!(s1 == 0 && s2 == 0)) {
+					if (!done3) {
 						// Q1 is numerically rank deficient (e.g. exactly dependent columns), or sweep 3 found Q2 short of the strict rule.
 						// Q holds Q1 (sweep 2 rejected: its apply pass skipped itself) or Q2 -- A may be gone (q may alias a), so the rest is
 						// done on Q in place by checked sweeps, which escalate per panel (fp64 Gram -> shifted -> Householder)
