@@ -30,3 +30,8 @@ for gi in range(min(4, (n + 3) // 4)):
     o, x, w0 = s[gi], s[oth], s[0]
     print("g%02d owner w%d: bar %5d %5d | after %5d %5d | period %5d" % (
         gi, gi, o[b + 2] - o[b + 1], x[b + 2] - x[b + 1], o[b + 3] - o[b + 2], x[b + 3] - x[b + 2], w0[b + 9] - w0[b + 1]))
+
+print("next owner's path (wave g+1 in iteration g): barrier release -> update done -> section arithmetic done -> rows published")
+for gi in range(min(3, (n + 3) // 4 - 1)):
+    o, b = s[gi + 1], 8 + 8 * gi
+    print("g%02d -> owner w%d: update %5d | section %5d | publish %5d | total %5d" % (gi, gi + 1, o[b + 4] - o[b + 2], o[b + 5] - o[b + 4], o[b + 7] - o[b + 5], o[b + 7] - o[b + 2]))

@@ -1193,10 +1193,11 @@ typedef double f64x2c __attribute__((ext_vector_type(2)));
 // traffic at all -- while the scalings and eliminations of its own column follow in the chain's shadow.  Same operations on the same
 // operands as before (the trailing matrix is exactly symmetric, so the private copy l[v][u] IS what lane K0+v computes for R[K0+u][K0+v]):
 // R, Z and the verdict are bit for bit those of rounds 1-3.
-//   out: rk[u] = R[K0+u][j], mk[u] = M[K0+u][j] (zero for rows >= n), piv0[u] = the pivot before clamping (verdict: pv[])
+//   out: rk[u] = R[K0+u][j], mk[u] = M[K0+u][j] (zero for rows >= n; also written to rr / mr, the group's published rows in LDS),
+//        piv0[u] = the pivot before clamping (verdict: pv[])
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void chol_section4(double (&g)[4], double (&mm)[4], const int K0, const int j, const int n,
-                                              double (&rk)[4], double (&mk)[4], double (&piv0)[4]) {
+                                              double (&rk)[4], double (&mk)[4], double (&piv0)[4], double* __restrict__ rr, double* __restrict__ mr) {
 	// a[u][v] = G'[K0+u][K0+v], v <= u: register u of lane K0+v
 	double a00 = bcast_lane_f64(g[0], K0);
 	double a10 = bcast_lane_f64(g[1], K0), a11 = bcast_lane_f64(g[1], K0 + 1);
@@ -1207,44 +1208,50 @@ __device__ __forceinline__ void chol_section4(double (&g)[4], double (&mm)[4], c
 		return fma(0.5 * y, fma(-piv * y, y, 1.0), y);       // one Newton step (v_rsq_f64 is good to ~2^-23: 2^-45 after it)
 	};
 	const bool live0 = K0 < n, live1 = K0 + 1 < n, live2 = K0 + 2 < n, live3 = K0 + 3 < n;
+	// Row K of R is g * y right of the diagonal, piv * y on it, zero left of it; row K of M is mm * y.  Every finished row is published
+	// (rr / mr: the group's rows in LDS) as soon as it exists: in-kernel stamps showed the LDS writes of a group taking ~500 cycles to be
+	// acknowledged behind the other waves' reads when all eight were issued at the end of the section.
 	// pivot 0
 	piv0[0] = a00;
 	const double p0 = (a00 > 0.0) ? a00 : 1.0;               // keeps the arithmetic finite; breakdown is flagged from pv[] afterwards
 	const double y0 = inv_sqrt(p0);
 	const double l10 = live0 ? a10 * y0 : 0.0, l20 = live0 ? a20 * y0 : 0.0, l30 = live0 ? a30 * y0 : 0.0;
+	rk[0] = !live0 ? 0.0 : ((j > K0) ? g[0] * y0 : ((j == K0) ? p0 * y0 : 0.0));
+	mk[0] = live0 ? mm[0] * y0 : 0.0;
+	rr[0 * 64 + j] = rk[0]; mr[0 * 64 + j] = mk[0];
 	a11 = fma(-l10, l10, a11); a21 = fma(-l20, l10, a21); a31 = fma(-l30, l10, a31);
 	a22 = fma(-l20, l20, a22); a32 = fma(-l30, l20, a32); a33 = fma(-l30, l30, a33);
+	g[1] = fma(-l10, rk[0], g[1]); mm[1] = fma(-l10, mk[0], mm[1]);
+	g[2] = fma(-l20, rk[0], g[2]); mm[2] = fma(-l20, mk[0], mm[2]);
+	g[3] = fma(-l30, rk[0], g[3]); mm[3] = fma(-l30, mk[0], mm[3]);
 	// pivot 1
 	piv0[1] = a11;
 	const double p1 = (a11 > 0.0) ? a11 : 1.0;
 	const double y1 = inv_sqrt(p1);
 	const double l21 = live1 ? a21 * y1 : 0.0, l31 = live1 ? a31 * y1 : 0.0;
+	rk[1] = !live1 ? 0.0 : ((j > K0 + 1) ? g[1] * y1 : ((j == K0 + 1) ? p1 * y1 : 0.0));
+	mk[1] = live1 ? mm[1] * y1 : 0.0;
+	rr[1 * 64 + j] = rk[1]; mr[1 * 64 + j] = mk[1];
 	a22 = fma(-l21, l21, a22); a32 = fma(-l31, l21, a32); a33 = fma(-l31, l31, a33);
+	g[2] = fma(-l21, rk[1], g[2]); mm[2] = fma(-l21, mk[1], mm[2]);
+	g[3] = fma(-l31, rk[1], g[3]); mm[3] = fma(-l31, mk[1], mm[3]);
 	// pivot 2
 	piv0[2] = a22;
 	const double p2 = (a22 > 0.0) ? a22 : 1.0;
 	const double y2 = inv_sqrt(p2);
 	const double l32 = live2 ? a32 * y2 : 0.0;
+	rk[2] = !live2 ? 0.0 : ((j > K0 + 2) ? g[2] * y2 : ((j == K0 + 2) ? p2 * y2 : 0.0));
+	mk[2] = live2 ? mm[2] * y2 : 0.0;
+	rr[2 * 64 + j] = rk[2]; mr[2 * 64 + j] = mk[2];
 	a33 = fma(-l32, l32, a33);
+	g[3] = fma(-l32, rk[2], g[3]); mm[3] = fma(-l32, mk[2], mm[3]);
 	// pivot 3
 	piv0[3] = a33;
 	const double p3 = (a33 > 0.0) ? a33 : 1.0;
 	const double y3 = inv_sqrt(p3);
-	// this lane's column: row K of R is g * y right of the diagonal, piv * y on it, zero left of it; row K of M is mm * y
-	rk[0] = !live0 ? 0.0 : ((j > K0) ? g[0] * y0 : ((j == K0) ? p0 * y0 : 0.0));
-	mk[0] = live0 ? mm[0] * y0 : 0.0;
-	g[1] = fma(-l10, rk[0], g[1]); mm[1] = fma(-l10, mk[0], mm[1]);
-	g[2] = fma(-l20, rk[0], g[2]); mm[2] = fma(-l20, mk[0], mm[2]);
-	g[3] = fma(-l30, rk[0], g[3]); mm[3] = fma(-l30, mk[0], mm[3]);
-	rk[1] = !live1 ? 0.0 : ((j > K0 + 1) ? g[1] * y1 : ((j == K0 + 1) ? p1 * y1 : 0.0));
-	mk[1] = live1 ? mm[1] * y1 : 0.0;
-	g[2] = fma(-l21, rk[1], g[2]); mm[2] = fma(-l21, mk[1], mm[2]);
-	g[3] = fma(-l31, rk[1], g[3]); mm[3] = fma(-l31, mk[1], mm[3]);
-	rk[2] = !live2 ? 0.0 : ((j > K0 + 2) ? g[2] * y2 : ((j == K0 + 2) ? p2 * y2 : 0.0));
-	mk[2] = live2 ? mm[2] * y2 : 0.0;
-	g[3] = fma(-l32, rk[2], g[3]); mm[3] = fma(-l32, mk[2], mm[3]);
 	rk[3] = !live3 ? 0.0 : ((j > K0 + 3) ? g[3] * y3 : ((j == K0 + 3) ? p3 * y3 : 0.0));
 	mk[3] = live3 ? mm[3] * y3 : 0.0;
+	rr[3 * 64 + j] = rk[3]; mr[3 * 64 + j] = mk[3];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1364,32 +1371,26 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 			g[u] = xv;
 			mm[u] = gpart ? mv : xv;
 		}
-		chol_section4(g, mm, K0, j, n, rk, mk, piv0);
+		chol_section4(g, mm, K0, j, n, rk, mk, piv0, rr, mr);
+		if (gi > 0) CHOL_STAMP16(8 + 8 * (gi - 1) + 5);
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
-			rr[u * 64 + j] = rk[u];
-			mr[u * 64 + j] = mk[u];
+		for (int u = 0; u < 4; u++)
 			if (j == 0 && K0 + u < n) pv[K0 + u] = piv0[u];
-		}
 	};
 	// rank-4 update of this wave's four rows with the published rows of group gi: R part first (an owner's pivots wait for it), then M
 	auto update = [&](int gi) __attribute__((always_inline)) {
 		const double* rr = Rrow + (gi & 1) * 256;
 		const double* mr = Mrow + (gi & 1) * 256;
-		double rki[4][4], rkj[4], mkc[4];
+		// (stamps, round 4: a group's period is the LDS pipe -- every wave behind the owner re-reads the published rows.  A lane needs
+		// row K of R where it holds G and row K of M where it holds M: ONE read per row from the array its side of the packing selects)
+		const double* yr = gpart ? rr : mr;
+		double rki[4][4], yv[4];
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 			const f64x2c a01 = *reinterpret_cast<const f64x2c*>(&rr[u * 64 + 4 * w]);
 			const f64x2c a23 = *reinterpret_cast<const f64x2c*>(&rr[u * 64 + 4 * w + 2]);
 			rki[u][0] = a01[0]; rki[u][1] = a01[1]; rki[u][2] = a23[0]; rki[u][3] = a23[1];      // R[K0+u][4w .. 4w+3]
-			rkj[u] = rr[u * 64 + j];
-			mkc[u] = mr[u * 64 + j];
-		}
-		double yv[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) {                    // G lanes take row K of R, M lanes row K of M
-			const double rv = rkj[u], mv = mkc[u];
-			yv[u] = gpart ? rv : mv;
+			yv[u] = yr[u * 64 + j];
 		}
 #pragma unroll
 		for (int sl = 0; sl < 4; sl++)
@@ -1407,7 +1408,9 @@ __device__ __forceinline__ void chol_body16(float* __restrict__ r, size_t ldr, f
 			// part in the pivot chain and fills the chain's latency gaps instead of standing in front of it.  (Round 4: raising this
 			// wave's issue priority with s_setprio for the length of the block changed nothing: 15.9 vs 15.7 us.)
 			update(gi);
+			CHOL_STAMP16(8 + 8 * gi + 4);
 			section(gi + 1);
+			CHOL_STAMP16(8 + 8 * gi + 7);
 		} else if (w > gi) {
 			update(gi);
 		}
@@ -1563,12 +1566,10 @@ __device__ __forceinline__ void chol_group4(double (&g)[16], double (&mm)[16], d
 		// are taken from the published rows by a wave that is off the path (below)
 		double g4[4] = {g[0], g[1], g[2], g[3]}, m4[4] = {mm[0], mm[1], mm[2], mm[3]};
 		double rk[4], mk[4], piv0[4];
-		chol_section4(g4, m4, K0, j, n, rk, mk, piv0);
+		chol_section4(g4, m4, K0, j, n, rk, mk, piv0, rr, mr);
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 			g[u] = g4[u]; mm[u] = m4[u];
-			rr[u * 64 + j] = rk[u];
-			mr[u * 64 + j] = mk[u];
 			if (j == 0 && K0 + u < n) pv[K0 + u] = piv0[u];
 		}
 	}
