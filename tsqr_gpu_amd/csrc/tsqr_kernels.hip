@@ -1997,6 +1997,12 @@ struct ApplyArgs {
 	int share[4];                       // all zero: blocks interleaved over the grid.  Otherwise (grid = four workgroups per CU, dispatched in four
 	                                    // rounds): 64ths of a CU's blocks for its first .. fourth workgroup (apply_wg_body) and
 	int even_share;                     // 128ths of the blocks of two neighbouring CUs (even XCD, odd XCD) for the one on the even XCD
+	int plain_q;                        // 1: Q leaves with plain (cache-allocating) stores and
+	int forward;                        // 1: the blocks are taken in ascending order (default: descending, nontemporal stores) -- the first sweep of a
+	                                    // reorthogonalised call: the sweep behind it walks Q in DESCENDING order and so starts with the blocks written
+	                                    // last, the half of Q the Infinity Cache still holds (round 4: C5 0.513 -> 0.498 ms, well-conditioned reorth
+	                                    // 0.364 -> 0.357; plain stores alone, same order in both sweeps, had gained nothing: round 3's and this round's
+	                                    // A/B -- the second sweep then starts with the blocks the cache has already dropped)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -2123,7 +2129,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 	}
 	auto blk = [&](int i) {                              // i: position in this workgroup's progression -> block (reverse order: as good as any)
 		const int ordinal = uneven ? pair_base + (i & 1) + quarter * (i >> 1) : i;
-		return nblk - 1 - ordinal;
+		return a.forward ? ordinal : nblk - 1 - ordinal;
 	};
 	if (bi < bend) load_block(v, a_in, a.lda, a.n, blk(bi));
 	if constexpr (DEEP) { if (bi + bstep < bend) load_block(v2, a_in, a.lda, a.n, blk(bi + bstep)); }
@@ -2431,7 +2437,7 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 					if (row + 3 < a.m) {
 						// Q must not displace A from the Infinity Cache: nontemporal.  The updated panel of a coupling step (UPD) is read
 						// again at once by its own Gram and apply passes: plain stores keep it there.
-						if constexpr (UPD) *reinterpret_cast<f32x4u*>(dst) = x;
+						if (UPD || a.plain_q) *reinterpret_cast<f32x4u*>(dst) = x;
 						else __builtin_nontemporal_store(x, reinterpret_cast<f32x4u*>(dst));
 					} else {
 #pragma unroll

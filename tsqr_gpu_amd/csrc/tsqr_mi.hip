@@ -271,6 +271,7 @@ struct Ctx {
 	int start_level = -1;                                // tsqr_mi_qr_f32_finish: the ladder resumes at this level (the ones above were rejected)
 	unsigned* announce_word = nullptr;                   // completion word of the call in front of this one, raised by this call's first
 	unsigned announce_seq = 0;                           // Gram kernel (consumed by the launch that carries it)
+	bool q_for_next_sweep = false;                       // apply launches write Q for a sweep that reads it back at once: plain stores, ascending block order (ApplyArgs)
 	int chol_relax = 0;                                  // the next bf16-level Cholesky launches use the relaxed rule (CholArgs::relax: another sweep follows)
 	int chol_retry_shift = 0;                            // ... and factor a rejected matrix again at once, shifted (CholArgs::retry_shift)
 	double rows_global = 0.0;                            // host's view of the global row count (the device thresholds of a row-partitioned
@@ -698,6 +699,7 @@ int apply_rinv(Ctx& c, int engine, float* q, size_t ldq, const float* a, size_t 
 	tsqrmi::ApplyArgs aa{};
 	aa.a = a; aa.lda = lda; aa.q = q; aa.ldq = ldq; aa.m = m; aa.n = (int)n; aa.z = z_buf; aa.skip_status = skip_status;
 	aa.r32 = r; aa.r16 = r16; aa.ldr16 = ldr16;         // (io_half with r16: r is then a packed n x n factor, ld n)
+	aa.plain_q = aa.forward = c.q_for_next_sweep ? 1 : 0;
 	int rc;
 	{
 		ProfScope ps(KC_APPLY, c.st);
@@ -1039,8 +1041,8 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 				//           Fukaya et al. 2020).  s = c trace(G), c = 8 * 2^-23 / sqrt(rows): four times the Frobenius bound of the bf16-split Gram
 				//           matrix's own error (products good to 2^-23, errors averaging over the rows: |dG_ij| ~ 2^-22 / sqrt(rows) sqrt(g_ii g_jj),
 				//           measured as 8e-6 S / sqrt(rows) in Q^T Q), so the fp64 Gram pass of A (108 us) and its rejected Cholesky are not needed.
-				//           -> Q1 = A inverse(R1), Gram tiles of Q1 from the same launch.  (Plain stores for Q1 were measured again: no hit gain
-				//           for the sweep behind it, and A is displaced from the Infinity Cache -- profiles/r03_experiment_log.md, r04.)
+				//           -> Q1 = A inverse(R1), Gram tiles of Q1 from the same launch; Q1 leaves with plain stores in ASCENDING block order, so
+				//           that sweep 2 (descending) starts with the half of Q1 the Infinity Cache still holds (ApplyArgs::forward).
 				//  The host reads sweep 1's verdict word WHILE the apply pass of sweep 1 runs, then enqueues
 				//  accepted plain   : sweep 2 under the strict rule -> Q, R = R2 R1 (CholeskyQR2: what rounds 1-3 did for such input);
 				//  accepted shifted : sweep 2 under the relaxed rule (cond(Q1) ~ 1 / sqrt(c): 1e3 .. 4e3) with Gram tiles of Q2 from its
@@ -1054,7 +1056,9 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 				c.slot = 0; c.prev_slot = -1;
 				hw[0] = PENDING;
 				c.chol_relax = 1; c.chol_retry_shift = 1;
+				c.q_for_next_sweep = (double)ldq * (double)n * sizeof(float) <= 300.0e6;      // (a Q the Infinity Cache can hold half of)
 				rc = sweep(c, engine, 2, /*check_now=*/false, q, ldq, r1, n, a, lda, m, n);
+				c.q_for_next_sweep = false;
 				c.chol_relax = 0; c.chol_retry_shift = 0;
 				const bool have_gramq = c.gramq_nparts > 0;
 				if (rc) { c.gramq_part = nullptr; c.gramq_cap = 0; return rc; }
