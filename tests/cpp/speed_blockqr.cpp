@@ -1,6 +1,8 @@
 // The reference's speed protocol (src/test.cu:257-343: one warm-up call, then wall clock over C = 16 blocking calls) from a C++
 // caller of include/tsqr/blockqr.hpp -- no Python, no torch: what a user of the reference sees after switching.  The first mode is
 // also timed as a stream of calls, two in flight (qr_submit / qr_finish).
+// also timed as a stream of calls, two in flight (qr_submit / qr_finish), and as ONE mtk::qr::qr_batch call over four different
+// matrices in rotation (the caller with many matrices; no call finds its A in the Infinity Cache from an earlier call).
 // Prints the reference's speed CSV line plus the algorithmic TFLOP/s (F_QR = 4MN^2 - 4/3 N^3).
 #include <chrono>
 #include <cstdio>
@@ -41,6 +43,27 @@ int speed(const std::size_t M, const std::size_t N, const unsigned C, const char
 		const auto t3 = std::chrono::system_clock::now();
 		const double el2 = std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count() * 1e-9 / C;
 		std::printf("%zu,%zu,1,float,%s/two_in_flight,%d,%e,%e,%zu\n", M, N, mode_name, (int)reorth, el2, fqr / el2 / 1e12, buffer.get_device_memory_size());
+	}
+	if (stream_of_calls) {
+		// C different-matrix calls through one mtk::qr::qr_batch call: four (A, Q, R) triples in rotation
+		constexpr int R = 4;
+		float *ra[R], *rq[R], *rr[R];
+		ra[0] = d_a; rq[0] = d_q; rr[0] = d_r;
+		for (int k = 1; k < R; k++) {
+			for (auto& v : h_a) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (float)((double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0); }
+			if (hipMalloc((void**)&ra[k], sizeof(float) * M * N) != hipSuccess || hipMalloc((void**)&rq[k], sizeof(float) * M * N) != hipSuccess ||
+			    hipMalloc((void**)&rr[k], sizeof(float) * N * N) != hipSuccess) return 1;
+			(void)hipMemcpy(ra[k], h_a.data(), sizeof(float) * M * N, hipMemcpyHostToDevice);
+		}
+		std::vector<float*> pa(C), pq(C), pr(C);
+		for (unsigned c = 0; c < C; c++) { pa[c] = ra[c % R]; pq[c] = rq[c % R]; pr[c] = rr[c % R]; }
+		if (mtk::qr::qr_batch<mode, reorth>(C, pq.data(), M, pr.data(), N, pa.data(), M, M, N, buffer, stream) != mtk::qr::success_factorization) return 1;   // warm-up
+		const auto t4 = std::chrono::system_clock::now();
+		if (mtk::qr::qr_batch<mode, reorth>(C, pq.data(), M, pr.data(), N, pa.data(), M, M, N, buffer, stream) != mtk::qr::success_factorization) return 1;
+		const auto t5 = std::chrono::system_clock::now();
+		const double el3 = std::chrono::duration_cast<std::chrono::nanoseconds>(t5 - t4).count() * 1e-9 / C;
+		std::printf("%zu,%zu,1,float,%s/qr_batch_4_rotating_matrices,%d,%e,%e,%zu\n", M, N, mode_name, (int)reorth, el3, fqr / el3 / 1e12, buffer.get_device_memory_size());
+		for (int k = 1; k < R; k++) { (void)hipFree(ra[k]); (void)hipFree(rq[k]); (void)hipFree(rr[k]); }
 	}
 	(void)hipFree(d_a); (void)hipFree(d_q); (void)hipFree(d_r); (void)hipStreamDestroy(stream);
 	return 0;

@@ -300,8 +300,9 @@ def test_cpp_sample_through_header(bq, torch_cuda):
         subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "speed_blockqr"])
     out = subprocess.run([spd, "65536", "64", "2"], capture_output=True, text=True, timeout=300)
     lines = out.stdout.strip().split("\n")
-    assert out.returncode == 0 and len(lines) == 5 and lines[1].startswith("65536,64,1,float,fp32_tc_cor,0,"), out.stdout + out.stderr
+    assert out.returncode == 0 and len(lines) == 6 and lines[1].startswith("65536,64,1,float,fp32_tc_cor,0,"), out.stdout + out.stderr
     assert lines[2].startswith("65536,64,1,float,fp32_tc_cor/two_in_flight,0,")      # the same calls through qr_submit / qr_finish
+    assert lines[3].startswith("65536,64,1,float,fp32_tc_cor/qr_batch_4_rotating_matrices,0,")   # four different matrices through mtk::qr::qr_batch
     assert all(float(l.split(",")[6]) > 0 for l in lines[1:])
 
 
