@@ -261,20 +261,25 @@ inline state_t qr_finish(ticket& t) {
 // computes -- bit for bit, including the fallback ladder of a matrix the conditioning check rejects -- issued as a stream: the 22 us
 // in which one workgroup factors the Gram matrix of matrix i are hidden in the Gram pass of matrix i + 1 (tsqr_mi.h for the rules:
 // q[i] and r[i] must be clear of a[i + 1] for that; in place, q[i] == a[i], is fine).  q, r, a: host arrays of device pointers.
-// states (optional): the state_t of every call.  Returns the first non-zero state_t.  fp32 I/O modes.
+// states (optional): the state_t of every call.  Returns the first non-zero state_t.  All implemented modes (half-typed pointers for the fp16 I/O modes).
 template <mtk::qr::compute_mode mode, bool Reorthogonalize>
 inline state_t qr_batch(
 		const std::size_t count,
-		float* const* const q_ptrs, const std::size_t ldq,
-		float* const* const r_ptrs, const std::size_t ldr,
-		float* const* const a_ptrs, const std::size_t lda,
+		typename mtk::qr::get_io_type<mode>::type* const* const q_ptrs, const std::size_t ldq,
+		typename mtk::qr::get_io_type<mode>::type* const* const r_ptrs, const std::size_t ldr,
+		typename mtk::qr::get_io_type<mode>::type* const* const a_ptrs, const std::size_t lda,
 		const std::size_t m, const std::size_t n,
 		buffer<mode, Reorthogonalize>& bf,
 		handle_t const stream = nullptr,
 		state_t* const states = nullptr) {
-	static_assert(std::is_same<typename mtk::qr::get_io_type<mode>::type, float>::value, "qr_batch takes the fp32 I/O modes");
-	const int st = tsqr_mi_qr_f32_batch(static_cast<int>(count), static_cast<int>(mode), Reorthogonalize ? 1 : 0, q_ptrs, ldq, r_ptrs, ldr, a_ptrs, lda, m, n,
-	                                    bf.dwq, bf.dwr, bf.dw_reorth_r, bf.dl, bf.hl, stream, states);
+	int st;
+	if constexpr (std::is_same<typename mtk::qr::get_io_type<mode>::type, float>::value)
+		st = tsqr_mi_qr_f32_batch(static_cast<int>(count), static_cast<int>(mode), Reorthogonalize ? 1 : 0, q_ptrs, ldq, r_ptrs, ldr, a_ptrs, lda, m, n,
+		                          bf.dwq, bf.dwr, bf.dw_reorth_r, bf.dl, bf.hl, stream, states);
+	else                                                  // the half-typed modes (same pointer arrays, elements are halves)
+		st = tsqr_mi_qr_f16_batch(static_cast<int>(count), static_cast<int>(mode), Reorthogonalize ? 1 : 0, reinterpret_cast<void* const*>(q_ptrs), ldq,
+		                          reinterpret_cast<void* const*>(r_ptrs), ldr, reinterpret_cast<const void* const*>(a_ptrs), lda, m, n,
+		                          bf.dwq, bf.dwr, bf.dw_reorth_r, bf.dl, bf.hl, stream, states);
 	if (st < 0) throw std::runtime_error(std::string("mtk::qr::qr_batch: ") + tsqr_mi_last_error());
 	return st;
 }

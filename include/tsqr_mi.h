@@ -183,6 +183,17 @@ int tsqr_mi_qr_f16_loop(int count, int mode, int reorth,
                         void* wq, void* wr, void* reorth_w, unsigned* d_wl, unsigned* h_wl,
                         void* stream);
 
+/* `count` DIFFERENT half-typed matrices of one shape: tsqr_mi_qr_f32_batch for the fp16 I/O modes (q, r, a: host arrays of device pointers to halves).
+ * Calls the native path takes (16 < n <= 64, no reorth, aligned halves, accepted by the bf16-split level) are issued as a stream -- two in flight, for
+ * n = 64 the chained schedule while q[i], r[i] are clear of a[i + 1] and a matrix is small enough for two to share the Infinity Cache --, everything else
+ * as blocking calls; a matrix rejected mid-stream gets its whole ladder (conversion path), the accepted ones around it stand.  The same halves as
+ * `count` calls of tsqr_mi_qr_f16.  states (optional): the state of every call.  Returns the first non-zero state. */
+int tsqr_mi_qr_f16_batch(int count, int mode, int reorth,
+                         void* const* q, size_t ldq, void* const* r, size_t ldr, const void* const* a, size_t lda,
+                         size_t m, size_t n,
+                         void* wq, void* wr, void* reorth_w, unsigned* d_wl, unsigned* h_wl,
+                         void* stream, int* states);
+
 /*
  * Staged entry points used by the row-partitioned multi-GPU path: every rank
  * factors its row block, the n x n R factors are all-gathered (RCCL), every rank folds the stack,

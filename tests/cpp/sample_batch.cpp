@@ -12,6 +12,13 @@
 static_assert(mtk::qr::get_tsqr_compute_mode<mtk::qr::fp32_tc_cor>() == mtk::tsqr::fp32_tc_cor, "mode mapping of reference src/blockqr.hpp:31-43");
 static_assert(mtk::qr::get_tsqr_compute_mode<mtk::qr::fp16_notc>() == mtk::tsqr::fp16_notc, "mode mapping of reference src/blockqr.hpp:31-43");
 
+// (the half-typed instantiation: mtk::qr::qr_batch<fp16_tc_nocor, false> takes arrays of half pointers and forwards to tsqr_mi_qr_f16_batch;
+// compiled here, run by tests/test_gpu_f16.py through the Python mirror)
+[[maybe_unused]] static mtk::qr::state_t half_batch(std::size_t K, mtk::qr::half_t* const* q, mtk::qr::half_t* const* r, mtk::qr::half_t* const* a,
+                                                    std::size_t M, std::size_t N, mtk::qr::buffer<mtk::qr::fp16_tc_nocor, false>& b) {
+	return mtk::qr::qr_batch<mtk::qr::fp16_tc_nocor, false>(K, q, M, r, N, a, M, M, N, b);
+}
+
 int main(int argc, char** argv) {
 	constexpr auto mode = mtk::qr::fp32_tc_cor;
 	const std::size_t M = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : (1u << 17);

@@ -208,3 +208,35 @@ def test_loop_entry_streams_the_native_path(bq, oracle, torch_cuda, m, n, kind, 
         res.append((d_q.cpu().numpy().copy(), d_r.cpu().numpy().copy(), eng))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
     assert np.isfinite(res[1][0].astype(np.float32)).all()
+
+
+@pytest.mark.parametrize("mode", ["fp16_tc_nocor", "fp16_notc"])
+@pytest.mark.parametrize("m,n,k,bad", [(1 << 15, 64, 5, ()), (1 << 15, 64, 5, (2,)), (1 << 15, 64, 4, (0, 3)), (9216, 48, 4, ()), (4096, 128, 3, ())])
+def test_batch_of_half_typed_matrices(bq, oracle, torch_cuda, m, n, k, bad, mode):
+    """tsqr_mi_qr_f16_batch / mtk::qr::qr_batch for the fp16 I/O modes: K different matrices through one call at loop depths 1 / 2 / 3
+    (chained for 2^k x 64, two in flight for other native shapes, blocking for the conversion path) -- bit for bit the K blocking calls,
+    also with matrices the bf16-split level rejects in the stream (they take the conversion path and its whole ladder)."""
+    torch = torch_cuda
+    md = bq.compute_mode[mode]
+    mats = [(oracle.matrix_with_cond(m, n, 1e6, seed=70 + i) if i in bad else oracle.uniform_matrix(m, n, seed=70 + i)).astype(np.float16) for i in range(k)]
+    want = [run_f16(bq, torch, a, md, False) for a in mats]
+    assert all(w[0] == 0 for w in want)
+    for depth in (1, 2, 3):
+        d_a = [torch.from_numpy(np.ascontiguousarray(a.T)).cuda() for a in mats]
+        d_q = [torch.full((n, m), float("nan"), dtype=torch.float16, device="cuda") for _ in mats]
+        d_r = [torch.full((n, n), float("nan"), dtype=torch.float16, device="cuda") for _ in mats]
+        bf = bq.buffer(md, False); bf.allocate(m, n)
+        bq.set_loop_depth(depth)
+        try:
+            st, states = bq.qr_batch(d_q, m, d_r, n, d_a, m, m, n, bf)
+        finally:
+            bq.set_loop_depth(3)
+        assert st == 0 and states == [0] * k
+        for i in range(k):
+            assert np.array_equal(d_q[i].cpu().numpy().T.view(np.int16), want[i][1].view(np.int16)), (depth, i)
+            assert np.array_equal(d_r[i].cpu().numpy().T.view(np.int16), want[i][2].view(np.int16)), (depth, i)
+            assert np.array_equal(d_a[i].cpu().numpy().T, mats[i])               # A untouched
+    with pytest.raises(TypeError):                                               # float32 tensors for a half-typed mode
+        bf = bq.buffer(md, False); bf.allocate(64, 16)
+        x = torch.zeros(16, 64, device="cuda")
+        bq.qr_batch([x], 64, [x], 16, [x], 64, 64, 16, bf)

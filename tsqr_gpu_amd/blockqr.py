@@ -47,7 +47,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist", "tsqr_mi_qr_f32_dist_cb",
     "tsqr_mi_qr_f32_loop", "tsqr_mi_qr_f32_dist_fn", "tsqr_mi_qr_f32_dist_fn_loop", "tsqr_mi_qr_f32_dist_cb_loop",
     "tsqr_mi_qr_f16", "tsqr_mi_qr_f16_loop", "tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16",
-    "tsqr_mi_qr_f32_submit", "tsqr_mi_qr_f32_finish", "tsqr_mi_set_loop_depth", "tsqr_mi_qr_f32_batch",
+    "tsqr_mi_qr_f32_submit", "tsqr_mi_qr_f32_finish", "tsqr_mi_set_loop_depth", "tsqr_mi_qr_f32_batch", "tsqr_mi_qr_f16_batch",
 ]
 
 
@@ -136,6 +136,8 @@ def lib():
     L.tsqr_mi_qr_f32_finish.argtypes = [ctypes.POINTER(Ticket)]
     L.tsqr_mi_qr_f32_batch.restype = ci
     L.tsqr_mi_qr_f32_batch.argtypes = [ci, ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.tsqr_mi_qr_f16_batch.restype = ci
+    L.tsqr_mi_qr_f16_batch.argtypes = L.tsqr_mi_qr_f32_batch.argtypes
     L.tsqr_mi_set_loop_depth.restype = None
     L.tsqr_mi_set_loop_depth.argtypes = [ci]
     L.tsqr_mi_qr_f16.restype = ci
@@ -351,14 +353,18 @@ def bind_loop(q, ldq, r, ldr, a, lda, m, n, bf, stream=None, mode=None, reorthog
 
 
 def bind_batch(qs, ldq, rs, ldr, as_, lda, m, n, bf, stream=None, mode=None, reorthogonalize=None):
-    """mtk::qr::qr_batch (tsqr_mi_qr_f32_batch): qs, rs, as_ are equally long sequences of float32 tensors, one (q, r, a) triple per
-    matrix, all of the shape m x n with the shared leading dimensions.  Returns a callable: call() factors every matrix (blocking) and
+    """mtk::qr::qr_batch (tsqr_mi_qr_f32_batch / tsqr_mi_qr_f16_batch): qs, rs, as_ are equally long sequences of float32 tensors
+    (float16 for the two fp16 I/O modes), one (q, r, a) triple per matrix, all of the shape m x n with the shared leading dimensions.  Returns a callable: call() factors every matrix (blocking) and
     returns (first non-zero state, [state of every call]).  The tensors, the buffer and the stream must stay alive while it is in use."""
     import torch
     mode = bf.mode if mode is None else compute_mode(mode)
     reorth = bf.reorthogonalize if reorthogonalize is None else bool(reorthogonalize)
     if mode in FP16_MODES:
-        raise TypeError("the batch entry takes the fp32 I/O modes")
+        if bf.mode not in FP16_MODES:
+            raise RuntimeError("the buffer was allocated for %s: an fp16 mode needs the larger work space of its own allocate()" % bf.mode.name)
+        for t in list(qs) + list(rs) + list(as_):
+            if t.dtype != torch.float16:
+                raise TypeError("%s takes float16 tensors (io type half, reference src/tsqr.hpp:38-39)" % mode.name)
     if not (len(qs) == len(rs) == len(as_)):
         raise ValueError("qr_batch: q, r and a must name the same number of matrices")
     if stream is None:
@@ -368,14 +374,14 @@ def bind_batch(qs, ldq, rs, ldr, as_, lda, m, n, bf, stream=None, mode=None, reo
     arr = lambda ts: (vp * max(count, 1))(*[t.data_ptr() for t in ts])
     pq, pr, pa = arr(qs), arr(rs), arr(as_)
     states = (ci * max(count, 1))()
-    fn = lib().tsqr_mi_qr_f32_batch
+    fn = lib().tsqr_mi_qr_f16_batch if mode in FP16_MODES else lib().tsqr_mi_qr_f32_batch
     args = (ci(count), ci(int(mode)), ci(int(reorth)), pq, sz(ldq), pr, sz(ldr), pa, sz(lda), sz(m), sz(n),
             vp(_ptr(bf.dwq)), vp(_ptr(bf.dwr)), vp(_ptr(bf.dw_reorth_r)), vp(_ptr(bf.dl)), vp(_ptr(bf.hl)), vp(stream.cuda_stream), states)
 
     def call():
         st = fn(*args)
         if st < 0:
-            raise RuntimeError("tsqr_mi_qr_f32_batch failed: %s" % last_error())
+            raise RuntimeError("tsqr_mi_qr_batch failed: %s" % last_error())
         return st, list(states[:count])
     call._keep = (list(qs), list(rs), list(as_), bf, stream, pq, pr, pa, states)
     return call

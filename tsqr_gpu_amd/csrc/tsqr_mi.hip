@@ -2080,11 +2080,14 @@ int tsqr_mi_qr_f16(int mode, int reorth, void* q, size_t ldq, void* r, size_t ld
 // Cholesky + verdict, apply pass (which also rounds R), the completion word of call i raised by the Gram kernel of call i + 1.  The
 // verdict words alternate between the two halves of the pinned words.  Returns -2 when the call is not one for the native path
 // (nothing enqueued); a rejected verdict drains the stream and finishes the count with blocking calls (conversion path, whole ladder).
-static int stream_of_calls_f16(int count, int mode, void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
+// (mt: the half-typed operands of the calls, carried as float* -- one triple for a loop, one per call for a batch)
+static int stream_of_calls_f16(const Mats& mt, int count, int mode, size_t ldq, size_t ldr, size_t lda,
                                size_t m, size_t n, void* wq_v, void* wr_v, unsigned* h_wl, void* stream) {
 	auto aligned16 = [](const void* p, size_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
 	const int emode = f16_engine_mode(mode);
-	if (emode < 0 || n > m || m == 0 || n == 0 || n > PW || n <= 16 || ldq < m || lda < m || ldr < n || !aligned16(a, lda) || !aligned16(q, ldq)) return NOT_MINE;
+	if (emode < 0 || n > m || m == 0 || n == 0 || n > PW || n <= 16 || ldq < m || lda < m || ldr < n) return NOT_MINE;
+	for (int i = 0; i < (mt.same() ? 1 : count); i++)
+		if (!aligned16(mt.a(i), lda) || !aligned16(mt.q(i), ldq)) return NOT_MINE;
 	Ctx c;
 	init_ctx(c, wq_v, wr_v, m, n, stream);
 	c.rows_global = (double)m;
@@ -2096,10 +2099,10 @@ static int stream_of_calls_f16(int count, int mode, void* q, size_t ldq, void* r
 	unsigned seq[2] = {0, 0};
 	// n = 64, three calls or more: the chained schedule (tsqr_mi_qr_f32_loop's, with gram_h_chain_kernel) -- the R-factor chain of call i
 	// inside the Gram launch of call i + 1, two sets of partials
-	Mats mt;                                             // (the chained launch order needs Q and R of call i clear of A of call i + 1: chain_order_safe)
-	mt.q0 = reinterpret_cast<float*>(q); mt.r0 = reinterpret_cast<float*>(r); mt.a0 = const_cast<float*>(reinterpret_cast<const float*>(a));
-	const bool chained = (n == PW && count >= 3 && g_set.loop_depth.load() >= 3 &&
-	                      chain_order_safe(mt, count, Call{mode, 0, ldq, ldr, lda, m, n, wq_v, wr_v, h_wl, stream}, sizeof(_Float16)));
+	// (the chained launch order needs Q and R of call i clear of A of call i + 1, and two different matrices must share the Infinity Cache)
+	const Call cl{mode, 0, ldq, ldr, lda, m, n, wq_v, wr_v, h_wl, stream};
+	const bool chained = (n == PW && count >= 3 && g_set.loop_depth.load() >= 3 && chain_order_safe(mt, count, cl, sizeof(_Float16)) &&
+	                      (mt.same() || (double)lda * (double)n * sizeof(_Float16) <= (double)g_set.chain_max_mib * 1048576.0));
 	const GramPlan g = gram_plan(m, n);
 	const int nelem = 10 * 256, nred = nelem / 16;
 	double* part[2] = {reinterpret_cast<double*>(c.wr), reinterpret_cast<double*>(c.wr) + (size_t)g.nblocks * nelem};
@@ -2107,7 +2110,7 @@ static int stream_of_calls_f16(int count, int mode, void* q, size_t ldq, void* r
 	if (chained) HIPCHK(hipMemsetAsync(ticket, 0, sizeof(unsigned), c.st));
 	auto gram_h_args = [&](int i) {
 		tsqrmi::GramArgs ga{};
-		ga.a = reinterpret_cast<const float*>(a); ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = g.nch; ga.cpw = g.cpw; ga.nwaves = g.nwaves;
+		ga.a = mt.a(i); ga.lda = lda; ga.m = m; ga.n = (int)n; ga.nchunks = g.nch; ga.cpw = g.cpw; ga.nwaves = g.nwaves;
 		ga.part = part[i & 1];
 		ga.announce = c.announce_word; ga.announce_seq = c.announce_seq; c.announce_word = nullptr;
 		return ga;
@@ -2143,11 +2146,11 @@ static int stream_of_calls_f16(int count, int mode, void* q, size_t ldq, void* r
 			}
 			HIPCHK(hipGetLastError());
 		} else {
-			rc = gram_g(c, reinterpret_cast<const float*>(a), lda, m, n, /*bf16=*/true, /*io_half=*/true);
+			rc = gram_g(c, mt.a(i), lda, m, n, /*bf16=*/true, /*io_half=*/true);
 			if (!rc) rc = chol_from_g(c, r32, n, n, 2);
 		}
-		if (!rc) rc = apply_rinv(c, engine, reinterpret_cast<float*>(q), ldq, reinterpret_cast<const float*>(a), lda, r32, n, m, n, /*z_ready=*/true,
-		                         c.status_dev(c.slot), /*io_half=*/true, r, ldr);
+		if (!rc) rc = apply_rinv(c, engine, mt.q(i), ldq, mt.a(i), lda, r32, n, m, n, /*z_ready=*/true,
+		                         c.status_dev(c.slot), /*io_half=*/true, mt.r(i), ldr);
 		if (rc) return rc;
 		unsigned sq = ++g_seq;
 		if (sq == 0) sq = ++g_seq;
@@ -2173,30 +2176,59 @@ static int stream_of_calls_f16(int count, int mode, void* q, size_t ldq, void* r
 				else if (e != hipErrorNotReady) HIPCHK(e);
 			}
 		}
-		if (words[4 * (i & 1)] != 0) {                   // rejected: drain, then this call and the rest as blocking calls
+		if (words[4 * (i & 1)] != 0) {
+			// rejected (its apply pass skipped itself: A and Q untouched): drain; this call as a blocking call (conversion path, whole
+			// ladder); the call behind it, enqueued in full, stands if it was accepted; the rest of the count as blocking calls
 			HIPCHK(hipStreamSynchronize(c.st));
+			const bool next_ok = i + 1 < count && words[4 * ((i + 1) & 1)] == 0;
+			int first = 0;
 			for (int k = i; k < count; k++) {
-				const int st = tsqr_mi_qr_f16(mode, 0, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, nullptr, nullptr, h_wl, stream);
-				if (st) return st;
+				int st = 0;
+				if (!(k == i + 1 && next_ok))
+					st = tsqr_mi_qr_f16(mode, 0, mt.q(k), ldq, mt.r(k), ldr, mt.a(k), lda, m, n, wq_v, wr_v, nullptr, nullptr, h_wl, stream);
+				if (st < 0) return st;
+				mt.state(k, st);
+				if (st && !first) first = st;
+				if (st && mt.same()) return st;
 			}
-			return TSQR_MI_SUCCESS;
+			return first;
 		}
+		mt.state(i, TSQR_MI_SUCCESS);
 	}
 	t_last_engine = 3;
 	return TSQR_MI_SUCCESS;
 }
 
-int tsqr_mi_qr_f16_loop(int count, int mode, int reorth, void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
-                        size_t m, size_t n, void* wq_v, void* wr_v, void* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
+static int calls_f16(const Mats& mt, int count, int mode, int reorth, size_t ldq, size_t ldr, size_t lda, size_t m, size_t n,
+                     void* wq_v, void* wr_v, void* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
 	if (count >= 2 && g_set.loop_depth.load() >= 2 && !reorth) {
-		const int st = stream_of_calls_f16(count, mode, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, h_wl, stream);
+		const int st = stream_of_calls_f16(mt, count, mode, ldq, ldr, lda, m, n, wq_v, wr_v, h_wl, stream);
 		if (st != NOT_MINE) return st;
 	}
+	int first = 0;
 	for (int i = 0; i < count; i++) {
-		const int st = tsqr_mi_qr_f16(mode, reorth, q, ldq, r, ldr, a, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
-		if (st) return st;
+		const int st = tsqr_mi_qr_f16(mode, reorth, mt.q(i), ldq, mt.r(i), ldr, mt.a(i), lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
+		mt.state(i, st);
+		if (st && !first) first = st;
+		if (st < 0 || (st && mt.same())) return st;
 	}
-	return TSQR_MI_SUCCESS;
+	return first;
+}
+int tsqr_mi_qr_f16_loop(int count, int mode, int reorth, void* q, size_t ldq, void* r, size_t ldr, const void* a, size_t lda,
+                        size_t m, size_t n, void* wq_v, void* wr_v, void* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream) {
+	Mats mt;
+	mt.q0 = reinterpret_cast<float*>(q); mt.r0 = reinterpret_cast<float*>(r); mt.a0 = const_cast<float*>(reinterpret_cast<const float*>(a));
+	return calls_f16(mt, count, mode, reorth, ldq, ldr, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
+}
+// `count` DIFFERENT half-typed matrices of one shape (tsqr_mi_qr_f32_batch's counterpart for the fp16 I/O modes): calls the native path
+// takes are issued as a stream, everything else as blocking calls; the same halves either way
+int tsqr_mi_qr_f16_batch(int count, int mode, int reorth, void* const* q, size_t ldq, void* const* r, size_t ldr, const void* const* a, size_t lda,
+                         size_t m, size_t n, void* wq_v, void* wr_v, void* reorth_w, unsigned* d_wl, unsigned* h_wl, void* stream, int* states) {
+	if (count < 0 || (count > 0 && (!q || !r || !a))) return TSQR_MI_ERROR_INVALID_SIZE;
+	Mats mt;                                             // (pointer arrays of the same layout: void* / float*, const or not)
+	mt.qs = reinterpret_cast<float* const*>(q); mt.rs = reinterpret_cast<float* const*>(r); mt.as = reinterpret_cast<float* const*>(const_cast<void* const*>(a));
+	mt.states = states;
+	return calls_f16(mt, count, mode, reorth, ldq, ldr, lda, m, n, wq_v, wr_v, reorth_w, d_wl, h_wl, stream);
 }
 
 // ---- row-partitioned TSQR: one call per rank, the same ladder as tsqr_mi_qr_f32 with the exchange hooks switched on ----
