@@ -266,6 +266,13 @@ int tsqr_mi_qr_f32_dist_fn_loop(int count, int mode, int reorth,
                                 size_t m_local, size_t n,
                                 void* wq, void* wr, float* gather_buf,
                                 void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream);
+/* *_batch: `count` DIFFERENT row-partitioned matrices of one shape (host arrays of device pointers; one block height per rank for all of them), issued as
+ * the stream of calls of the *_loop entries; every rank passes the same count and operands of the same eligibility.  states (optional): per call. */
+int tsqr_mi_qr_f32_dist_fn_batch(int count, int mode, int reorth,
+                                 float* const* q, size_t ldq, float* const* r, size_t ldr, float* const* a, size_t lda,
+                                 size_t m_local, size_t n,
+                                 void* wq, void* wr, float* gather_buf,
+                                 void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream, int* states);
 typedef int (*tsqr_mi_allreduce_f64_cb)(void* user, double* buf /* device */, size_t count, void* stream);
 typedef int (*tsqr_mi_allgather_f32_cb)(void* user, const float* send /* device */, float* recv /* device, nranks*count */, size_t count, void* stream);
 int tsqr_mi_qr_f32_dist_cb(int mode, int reorth,
@@ -278,6 +285,11 @@ int tsqr_mi_qr_f32_dist_cb_loop(int count, int mode, int reorth,
                                 size_t m_local, size_t n,
                                 void* wq, void* wr, float* gather_buf,
                                 tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream);
+int tsqr_mi_qr_f32_dist_cb_batch(int count, int mode, int reorth,
+                                 float* const* q, size_t ldq, float* const* r, size_t ldr, float* const* a, size_t lda,
+                                 size_t m_local, size_t n,
+                                 void* wq, void* wr, float* gather_buf,
+                                 tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream, int* states);
 
 /* Harness support (reference src/validation.cu:43-127, src/test.cu:147-165): accuracy metrics evaluated on the device in fp64.
  * scratch: n*n + 8 doubles of device memory.  out_host[0..4] = ||Q^T Q - I||_F^2, its diagonal part, its off-diagonal part,

@@ -63,14 +63,14 @@ def _free_port():
     return p
 
 
-def _run(heights, n, mode="fp32_tc_cor", reorth=False, policy=0, cond=1.0, loop=0):
+def _run(heights, n, mode="fp32_tc_cor", reorth=False, policy=0, cond=1.0, loop=0, worker=None):
     import queue
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
     world = len(heights)                                      # (at most 4 here: the GPU box allows 6 processes on its card)
-    procs = [ctx.Process(target=_guarded, args=(r, world, port, heights, n, mode, reorth, policy, cond, loop, out)) for r in range(world)]
+    procs = [ctx.Process(target=_guarded, args=(worker or _worker, r, world, port, heights, n, mode, reorth, policy, cond, loop, out)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -101,10 +101,10 @@ def _run(heights, n, mode="fp32_tc_cor", reorth=False, policy=0, cond=1.0, loop=
                 p.join(timeout=10)
 
 
-def _guarded(rank, *args):
+def _guarded(worker, rank, *args):
     out = args[-1]
     try:
-        _worker(rank, *args)
+        worker(rank, *args)
     except BaseException as e:                                # surfaces at once in the parent instead of after its timeout
         import traceback
         out.put({"error": "rank %d: %s\n%s" % (rank, e, traceback.format_exc())})
@@ -210,3 +210,50 @@ def test_stream_of_row_partitioned_calls(oracle, heights, cond, loop):
         assert np.abs(np.tril(r, -1)).max() == 0.0
         assert np.linalg.norm(q @ r - a) / np.linalg.norm(a) < 2e-6
         assert np.linalg.norm(q.T @ q - np.eye(64)) < 1e-2                 # (cond 1e7..1e8 after rounding, no reorthogonalisation)
+
+
+def _batch_worker(rank, world, port, heights, n, mode, reorth, policy, cond, loop, out):
+    """`loop` DIFFERENT global matrices (matrix number 1 is ill conditioned when cond > 1): every rank factors its blocks one call after
+    the other, then all of them through one qr_batch call (tsqr_mi_qr_f32_dist_cb_batch) at loop depth 3 -- same bits on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tsqr_gpu_amd import blockqr as bq, dist as tdist
+    rng = np.random.Generator(np.random.MT19937(11))
+    m_glob = sum(heights)
+    row0 = sum(heights[:rank]); m_local = heights[rank]
+    mats = []
+    for k in range(loop):
+        a_glob = rng.uniform(-1, 1, size=(m_glob, n)).astype(np.float32)
+        if cond > 1 and k == 1:
+            u, _ = np.linalg.qr(rng.standard_normal((m_glob, n)))
+            v, _ = np.linalg.qr(rng.standard_normal((n, n)))
+            a_glob = ((u * np.geomspace(1.0, 1.0 / cond, n)) @ v.T).astype(np.float32)
+        mats.append(a_glob)
+    d_a = [torch.from_numpy(np.ascontiguousarray(a[row0:row0 + m_local].T)).cuda() for a in mats]
+    drv = tdist.RowPartitionedQR(bq.compute_mode[mode], m_local, n, comm="callbacks")
+    q1 = [torch.empty(n, m_local, device="cuda") for _ in mats]; r1 = [torch.zeros(n, n, device="cuda") for _ in mats]
+    st1 = [drv.qr(q, m_local, r, a, m_local, reorthogonalize=reorth) for q, r, a in zip(q1, r1, d_a)]
+    q2 = [torch.full((n, m_local), float("nan"), device="cuda") for _ in mats]; r2 = [torch.zeros(n, n, device="cuda") for _ in mats]
+    st2, states = drv.qr_batch(q2, m_local, r2, d_a, m_local, reorthogonalize=reorth)
+    torch.cuda.synchronize()
+    same = all(torch.equal(a, b) for a, b in zip(q1, q2)) and all(torch.equal(a, b) for a, b in zip(r1, r2))
+    flag = torch.tensor([1 if (same and st2 == 0 and states == [0] * loop and st1 == [0] * loop) else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    rs = [torch.zeros(n, n) for _ in range(world)]
+    dist.all_gather(rs, r2[-1].cpu())
+    if rank == 0:
+        out.put({"ok": int(flag.item()), "r_same": all(torch.equal(rs[0], t) for t in rs), "engine": drv.last_engine})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("heights,cond,k", [((32768, 16384), 1.0, 4), ((32768, 16384), 1e9, 5), ((30000, 17777), 1.0, 3), ((16384, 8192, 32768), 1e9, 4)])
+def test_batch_of_row_partitioned_matrices(heights, cond, k):
+    """tsqr_mi_qr_f32_dist_cb_batch: K different global matrices, every rank its row blocks, through one call per rank -- the chained
+    row-partitioned schedule over distinct operands where every rank is eligible (blocks of 128 k rows), two in flight otherwise, a
+    rejected matrix in the stream (all ranks take its ladder alike): bit for bit the K single calls, on every rank."""
+    res = _run(heights, 64, cond=cond, loop=k, worker=_batch_worker)
+    assert res["ok"] == 1 and res["r_same"]

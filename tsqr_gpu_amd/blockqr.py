@@ -48,6 +48,7 @@ C_ABI_SYMBOLS = [
     "tsqr_mi_qr_f32_loop", "tsqr_mi_qr_f32_dist_fn", "tsqr_mi_qr_f32_dist_fn_loop", "tsqr_mi_qr_f32_dist_cb_loop",
     "tsqr_mi_qr_f16", "tsqr_mi_qr_f16_loop", "tsqr_mi_working_q_size_f16", "tsqr_mi_working_r_size_f16",
     "tsqr_mi_qr_f32_submit", "tsqr_mi_qr_f32_finish", "tsqr_mi_set_loop_depth", "tsqr_mi_qr_f32_batch", "tsqr_mi_qr_f16_batch",
+    "tsqr_mi_qr_f32_dist_fn_batch", "tsqr_mi_qr_f32_dist_cb_batch",
 ]
 
 
@@ -153,6 +154,11 @@ def lib():
     L.tsqr_mi_qr_f32_dist_fn_loop.argtypes = [ci] + L.tsqr_mi_qr_f32_dist_fn.argtypes
     L.tsqr_mi_qr_f32_dist_cb_loop.restype = ci
     L.tsqr_mi_qr_f32_dist_cb_loop.argtypes = [ci] + L.tsqr_mi_qr_f32_dist_cb.argtypes
+    # (count, mode, reorth, q[], ldq, r[], ldr, a[], lda, m_local, n, wq, wr, gather, <transport: 3 x void*>, nranks, stream, states)
+    L.tsqr_mi_qr_f32_dist_fn_batch.restype = ci
+    L.tsqr_mi_qr_f32_dist_fn_batch.argtypes = [ci, ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, ci, vp, vp]
+    L.tsqr_mi_qr_f32_dist_cb_batch.restype = ci
+    L.tsqr_mi_qr_f32_dist_cb_batch.argtypes = [ci, ci, ci, vp, sz, vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, ci, vp, vp]
     for name in ("tsqr_mi_working_q_size_dist", "tsqr_mi_working_r_size_dist"):
         getattr(L, name).restype = sz
         getattr(L, name).argtypes = [sz, sz, ci]

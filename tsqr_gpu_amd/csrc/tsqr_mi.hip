@@ -2297,6 +2297,42 @@ int tsqr_mi_qr_f32_dist_cb_loop(int count, int mode, int reorth, float* q, size_
 	return stream_of_calls(env, mt, count, Call{mode, reorth, ldq, ldr, lda, m_local, n, wq_v, wr_v, nullptr, stream});
 }
 
+// `count` DIFFERENT row-partitioned matrices (every rank: its row block of each; one block height for all): the stream of calls of the
+// loop entries over one (q, r, a) triple per call.  Every rank passes the same count, the same loop depth and operands of the same
+// eligibility (alignment, overlap) on the same calls' positions -- the verdicts, and so the path through the batch, are the same on
+// all ranks by construction (they come from the all-reduced matrix).
+int tsqr_mi_qr_f32_dist_fn_batch(int count, int mode, int reorth, float* const* q, size_t ldq, float* const* r, size_t ldr, float* const* a, size_t lda,
+                                 size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
+                                 void* nccl_comm, void* nccl_allreduce_fn, void* nccl_allgather_fn, int nranks, void* stream, int* states) {
+	if (!nccl_comm || !nccl_allreduce_fn || !nccl_allgather_fn) {
+		t_last_error = "row-partitioned call needs an ncclComm_t and the ncclAllReduce / ncclAllGather entry points of the library that created it";
+		return TSQR_MI_ERROR_UNSUPPORTED;
+	}
+	if (count < 0 || (count > 0 && (!q || !r || !a))) return TSQR_MI_ERROR_INVALID_SIZE;
+	CallEnv env;
+	env.dist = true; env.nranks = nranks;
+	env.comm.nccl = nccl_comm;
+	env.comm.nccl_allreduce = reinterpret_cast<nccl_allreduce_t>(nccl_allreduce_fn);
+	env.comm.nccl_allgather = reinterpret_cast<nccl_allgather_t>(nccl_allgather_fn);
+	env.comm.gather_buf = gather_buf;
+	Mats mt;
+	mt.qs = q; mt.rs = r; mt.as = a; mt.states = states;
+	return stream_of_calls(env, mt, count, Call{mode, reorth, ldq, ldr, lda, m_local, n, wq_v, wr_v, nullptr, stream});
+}
+int tsqr_mi_qr_f32_dist_cb_batch(int count, int mode, int reorth, float* const* q, size_t ldq, float* const* r, size_t ldr, float* const* a, size_t lda,
+                                 size_t m_local, size_t n, void* wq_v, void* wr_v, float* gather_buf,
+                                 tsqr_mi_allreduce_f64_cb allreduce, tsqr_mi_allgather_f32_cb allgather, void* user, int nranks, void* stream, int* states) {
+	if (!allreduce || !allgather) return TSQR_MI_ERROR_UNSUPPORTED;
+	if (count < 0 || (count > 0 && (!q || !r || !a))) return TSQR_MI_ERROR_INVALID_SIZE;
+	CallEnv env;
+	env.dist = true; env.nranks = nranks;
+	env.comm.cb_allreduce = allreduce; env.comm.cb_allgather = allgather; env.comm.cb_user = user;
+	env.comm.gather_buf = gather_buf;
+	Mats mt;
+	mt.qs = q; mt.rs = r; mt.as = a; mt.states = states;
+	return stream_of_calls(env, mt, count, Call{mode, reorth, ldq, ldr, lda, m_local, n, wq_v, wr_v, nullptr, stream});
+}
+
 // ---- staged entry points (building blocks; every call builds its own context) ----
 int tsqr_mi_local_r_f32(float* r, size_t ldr, const float* a, size_t lda, size_t m, size_t n,
                         void* wq, void* wr, void* stream) {

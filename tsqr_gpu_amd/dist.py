@@ -235,6 +235,40 @@ class HipBackend:
         return call
 
 
+    def bind_batch(self, qs, ldq, rs, ldr, as_, lda, m_local, reorth):
+        """`len(as_)` DIFFERENT row-partitioned matrices through one C call (tsqr_mi_qr_f32_dist_{fn,cb}_batch): returns a callable giving
+        (first non-zero state, [states]).  Every rank binds the same number of matrices."""
+        self._check_block(m_local)
+        if not (len(qs) == len(rs) == len(as_)):
+            raise ValueError("qr_batch: q, r and a must name the same number of matrices")
+        st = torch.cuda.current_stream()
+        count = len(as_)
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        arr = lambda ts: (vp * max(count, 1))(*[t.data_ptr() for t in ts])
+        pq, pr, pa = arr(qs), arr(rs), arr(as_)
+        states = (ci * max(count, 1))()
+        L = bq.lib()
+        head = (ci(count), ci(int(self.mode)), ci(int(reorth)), pq, sz(ldq), pr, sz(ldr), pa, sz(lda), sz(m_local), sz(self.n),
+                vp(self.wq.data_ptr()), vp(self.wr.data_ptr()), vp(self.gather.data_ptr()))
+        if self.comm is not None:
+            fn = L.tsqr_mi_qr_f32_dist_fn_batch
+            args = head + (self.comm.comm, self.comm.allreduce_fn, self.comm.allgather_fn, ci(self.world), vp(st.cuda_stream), states)
+        else:
+            fn = L.tsqr_mi_qr_f32_dist_cb_batch
+            args = head + (ctypes.cast(self._ar, vp), ctypes.cast(self._ag, vp), None, ci(self.world), vp(st.cuda_stream), states)
+
+        def call():
+            self._cb_error = None
+            rc = fn(*args)
+            if self._cb_error is not None:
+                raise self._cb_error
+            if rc < 0:
+                raise RuntimeError("tsqr_mi_qr_f32_dist_batch failed: %s" % bq.last_error())
+            return rc, list(states[:count])
+        call._keep = (list(qs), list(rs), list(as_), st, self, pq, pr, pa, states)
+        return call
+
+
 class RowPartitionedQR:
     """mtk::qr::qr for a matrix whose rows are spread over the ranks of `group`.
 
@@ -310,6 +344,15 @@ class RowPartitionedQR:
 
     def bind_loop(self, q, ldq, r, a, lda, reorthogonalize=False, m_local=None):
         return self.bind(q, ldq, r, a, lda, reorthogonalize, m_local, loop=True)
+
+    def qr_batch(self, qs, ldq, rs, as_, lda, reorthogonalize=False):
+        """Several DIFFERENT row-partitioned matrices (this rank's block of each, the constructor's block height) through one C call, as the
+        stream of calls the loop entry issues.  Collective: every rank passes the same number of matrices.  Returns (first non-zero state,
+        [state of every call])."""
+        if not hasattr(self.backend, "bind_batch"):
+            states = [self.qr(q, ldq, r, a, lda, reorthogonalize) for q, r, a in zip(qs, rs, as_)]
+            return next((s for s in states if s), 0), states
+        return self.backend.bind_batch(qs, ldq, rs, self.n, as_, lda, self.m_local, bool(reorthogonalize))()
 
     @property
     def last_engine(self):
