@@ -14,7 +14,8 @@ import enum
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtsqr_mi.so")
+# TSQR_MI_LIB: another build of the library (same-box A/B of two builds, tools/r04_ab.sh); default: the in-tree one
+LIB_PATH = os.environ.get("TSQR_MI_LIB") or os.path.join(_HERE, "csrc", "libtsqr_mi.so")
 
 
 class compute_mode(enum.IntEnum):

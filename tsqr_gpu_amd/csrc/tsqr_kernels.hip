@@ -209,7 +209,10 @@ __device__ __forceinline__ float fast_rcp(float a) {     // v_rcp_f32 + one Newt
 // column inner products x_k^T x_c of a panel step (sixteen floats per wave) and V^T B of a block reflector (one accumulator tile
 // per wave and trailing tile).  Every wave adds the partial results of all waves in the same fixed order, so all of them hold
 // bit-identical reflectors and update their own copy of R in LDS identically -- no shared state besides the two exchange arrays.
-constexpr int FOLD_COOP_WAVES = 8;
+#ifndef TSQR_FOLD_COOP_WAVES
+#define TSQR_FOLD_COOP_WAVES 8
+#endif
+constexpr int FOLD_COOP_WAVES = TSQR_FOLD_COOP_WAVES;    // (the macro: experiments with the fan-in, profiles/r04_experiment_log.md)
 struct CoopCtx {
 	float* xd;                           // [2][WAVES][64]: column inner products of a step, double buffered by the step's parity
 	float* xw;                           // [3][WAVES][64][4]: V^T B accumulator tiles of a panel's trailing tiles
@@ -1730,6 +1733,13 @@ __device__ __forceinline__ void chol_body4(float* __restrict__ r, size_t ldr, fl
 // as the launch of its own) and take a ticket; the one that draws the last ticket factors (last-adder pattern: no workgroup ever
 // waits for another).  All other workgroups are the Gram pass of the next call, numbered from 0 as in gram_blk_kernel.
 // ---------------------------------------------------------------------------------------------
+// The hand-over of the reduced sums inside these launches (write-through stores, `s_waitcnt vmcnt(0)`, a relaxed ticket, device-scope loads)
+// is NOT a release / acquire pair of the HIP memory model: it relies on gfx9's store accounting -- `vmcnt` counts stores, and a store with
+// `sc1` is acknowledged only once it is visible device-wide -- which gfx10+ (a separate store counter) does not give.  This library is
+// built for gfx950 only; any other device target must not compile this file silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "tsqr_kernels.hip: the chained launches rely on gfx942 / gfx950 memory-counter semantics (vmcnt covers stores); port the hand-over before building for another target"
+#endif
 struct ChainArgs {
 	CholArgs chol;                       // (level 2; chol.gsum receives the reduced matrix)
 	const double* part; int nparts;      // Gram partials of the call being factored
@@ -2527,16 +2537,20 @@ __global__ __launch_bounds__(256) void rmul_kernel(float* __restrict__ r, size_t
 // of one per term), wave w forms the 16 x 16 tile (w >> 2, w & 3) of R2 R1 with v_mfma_f64_16x16x4_f64 over the k range in which
 // both triangular factors are non-zero.  12-14 us -> ~5 us in a reorthogonalised call.
 __global__ __launch_bounds__(1024) void rmul64_kernel(float* __restrict__ r, size_t ldr, const float* __restrict__ r2, size_t ldr2,
-                                                      const float* __restrict__ r1, size_t ldr1, int n) {
+                                                      const float* __restrict__ r1, size_t ldr1, int n,
+                                                      const float* __restrict__ r3 = nullptr, size_t ldr3 = 0) {
+	// r3 != nullptr (round 4, shifted CholeskyQR3: R = R3 R2 R1): both products in this launch, the inner one handed on through LDS in
+	// fp64 (as two launches the chain cost 2 x 6.1 us at the end of the call, behind the last apply pass)
 	__shared__ double A2[64 * 65], A1[64 * 65];          // A2[i * 65 + k] = R2[i][k], A1[k * 65 + j] = R1[k][j]; zero outside the upper triangles
 	const int t = threadIdx.x;
-	float v2[4], v1[4];
+	float v2[4], v1[4], v3[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++) {                        // (loads first, all in flight)
 		const int e = t + 1024 * u, i = e & 63, j = e >> 6;      // entry (i, j) of either factor, column-major
 		const bool in = i <= j && j < n;
 		v2[u] = in ? r2[(size_t)j * ldr2 + i] : 0.0f;
 		v1[u] = in ? r1[(size_t)j * ldr1 + i] : 0.0f;
+		v3[u] = (in && r3) ? r3[(size_t)j * ldr3 + i] : 0.0f;
 	}
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
@@ -2550,6 +2564,25 @@ __global__ __launch_bounds__(1024) void rmul64_kernel(float* __restrict__ r, siz
 	if (ti <= tj) {
 		for (int ks = 4 * ti; ks < 4 * (tj + 1); ks++)   // R2[i][k] = 0 for k < i, R1[k][j] = 0 for k > j
 			c = __builtin_amdgcn_mfma_f64_16x16x4f64(A2[(16 * ti + li) * 65 + 4 * ks + lq], A1[(4 * ks + lq) * 65 + 16 * tj + li], c, 0, 0, 0);
+	}
+	if (r3) {                                            // (uniform)
+		__syncthreads();                                 // every wave is done with R2 and R1
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++) {
+			const int i = 16 * ti + lq + 4 * reg, j = 16 * tj + li;
+			A1[i * 65 + j] = (i <= j) ? c[reg] : 0.0;    // P = R2 R1 (upper triangular), fp64
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int e = t + 1024 * u, i = e & 63, j = e >> 6;
+			A2[i * 65 + j] = (double)v3[u];
+		}
+		__syncthreads();
+		c = f64x4{0.0, 0.0, 0.0, 0.0};
+		if (ti <= tj) {
+			for (int ks = 4 * ti; ks < 4 * (tj + 1); ks++)
+				c = __builtin_amdgcn_mfma_f64_16x16x4f64(A2[(16 * ti + li) * 65 + 4 * ks + lq], A1[(4 * ks + lq) * 65 + 16 * tj + li], c, 0, 0, 0);
+		}
 	}
 #pragma unroll
 	for (int reg = 0; reg < 4; reg++) {

@@ -721,11 +721,20 @@ int engine_of(int mode) {
 // r <- r2 * r1 (upper triangular n x n, fp64 accumulation; r may not alias r1 / r2)
 void launch_rmul(float* r, size_t ldr, const float* r2, size_t ldr2, const float* r1, size_t ldr1, size_t n, hipStream_t st) {
 	if (n <= 64) {
-		hipLaunchKernelGGL(tsqrmi::rmul64_kernel, dim3(1), dim3(1024), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
+		hipLaunchKernelGGL(tsqrmi::rmul64_kernel, dim3(1), dim3(1024), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n, (const float*)nullptr, (size_t)0);
 		return;
 	}
 	const unsigned gb = (unsigned)std::min<size_t>(1024, cdiv(n * n, 256));
 	hipLaunchKernelGGL(tsqrmi::rmul_kernel, dim3(gb), dim3(256), 0, st, r, ldr, r2, ldr2, r1, ldr1, (int)n);
+}
+// r <- r3 * r2 * r1 (n <= 64: one launch, the inner product stays in LDS as fp64; otherwise through tmp, n x n packed)
+void launch_rmul3(float* r, size_t ldr, const float* r3, const float* r2, const float* r1, float* tmp, size_t n, hipStream_t st) {
+	if (n <= 64) {
+		hipLaunchKernelGGL(tsqrmi::rmul64_kernel, dim3(1), dim3(1024), 0, st, r, ldr, r2, n, r1, n, (int)n, r3, n);
+		return;
+	}
+	launch_rmul(tmp, n, r2, n, r1, n, n, st);
+	launch_rmul(r, ldr, r3, n, tmp, n, n, st);
 }
 
 // Householder TSQR R factor of one <= 64-column panel.  Row-partitioned: every rank folds its block, the n x n factors are
@@ -1118,8 +1127,7 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 						}
 						c.slot = 0; c.prev_slot = -1;
 						if (rc) return rc;
-						launch_rmul(r4, n, r2, n, r1, n, n, c.st);
-						launch_rmul(r, ldr, r3, n, r4, n, n, c.st);
+						launch_rmul3(r, ldr, r3, r2, r1, r4, n, c.st);
 						HIPCHK(hipGetLastError());
 						rc = read_status(c, 0, &s2);
 						if (rc) return rc;
@@ -1138,8 +1146,7 @@ int qr_core(Ctx& c, int engine, int reorth, float* q, size_t ldq, float* r, size
 						}
 						rc = sweep(c, engine, 2, /*check_now=*/true, q, ldq, r3, n, q, ldq, m, n);
 						if (rc) return rc;
-						launch_rmul(r4, n, r2, n, r1, n, n, c.st);
-						launch_rmul(r, ldr, r3, n, r4, n, n, c.st);
+						launch_rmul3(r, ldr, r3, r2, r1, r4, n, c.st);
 						HIPCHK(hipGetLastError());
 						rc = wait_done(c);
 						if (rc) return rc;
