@@ -1825,7 +1825,9 @@ __global__ __launch_bounds__(256) void gram_h_chain_kernel(const GramArgs a, con
 struct CrossArgs {
 	const float* x; size_t ldx; const float* y; size_t ldy; size_t m; int ny;     // X: m x 64, Y: m x ny
 	int nchunks; int cpw; int nwaves;
-	double* part;                        // [gridDim.x][16][256]
+	double* part;                        // [gridDim.y][gridDim.x][16][256]
+	int ny_total;                        // > 0 (round 4, right-looking coupling): Y is the WHOLE trailing matrix, m x ny_total; workgroups (., j) take its
+	                                     // 64-column panel j (the last one may be narrower) -- one launch per finished panel instead of one per panel pair
 };
 
 __global__ __launch_bounds__(256, 2) void cross_kernel(const CrossArgs a) {
@@ -1834,6 +1836,8 @@ __global__ __launch_bounds__(256, 2) void cross_kernel(const CrossArgs a) {
 	const int wv = threadIdx.x >> 6;
 	const int gw = blockIdx.x * 4 + wv;
 	const int c = lane & 15, q = lane >> 4;
+	const float* const ypan = a.y + (size_t)blockIdx.y * 64 * a.ldy;                     // (blockIdx.y == 0 unless ny_total is set)
+	const int ny = a.ny_total > 0 ? min(64, a.ny_total - 64 * (int)blockIdx.y) : a.ny;
 	f32x4 acc[16];
 #pragma unroll
 	for (int t = 0; t < 16; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1842,7 +1846,7 @@ __global__ __launch_bounds__(256, 2) void cross_kernel(const CrossArgs a) {
 		for (int ch = gw * a.cpw; ch < ch_end; ch++) {
 			float px[4][16], py[4][16];
 			load_chunk<4>(px, a.x, a.ldx, (size_t)ch * 64, a.m, 64, c, q);
-			load_chunk<4>(py, a.y, a.ldy, (size_t)ch * 64, a.m, a.ny, c, q);
+			load_chunk<4>(py, ypan, a.ldy, (size_t)ch * 64, a.m, ny, c, q);
 #pragma unroll
 			for (int kt = 0; kt < 2; kt++) {                 // K-step of 32 rows: registers 8kt .. 8kt+7 of every lane (as gram_bf16_kernel)
 				bf16x8 xh[4], xm[4], xl[4], yh[4], ym[4], yl[4];
@@ -1900,7 +1904,7 @@ __global__ __launch_bounds__(256, 2) void cross_kernel(const CrossArgs a) {
 	}
 	__syncthreads();
 	if (wv == 0) {
-		double* out = a.part + (size_t)blockIdx.x * 16 * 256;
+		double* out = a.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 * 256;
 #pragma unroll
 		for (int t = 0; t < 16; t++)
 #pragma unroll
@@ -1908,9 +1912,27 @@ __global__ __launch_bounds__(256, 2) void cross_kernel(const CrossArgs a) {
 	}
 }
 
+// the reduction of cross_kernel's partials for ALL trailing panels of a finished panel in one launch (grid (256, trailing panels)):
+// slice j sums its nparts partials exactly as gram_reduce1_kernel does (same body) into gout + j * CROSS_GSTRIDE and -- one GPU -- writes
+// the block of R (rows of the finished panel, columns of trailing panel j) and the operand -S of the update (fin_zneg + j * 4096)
+constexpr int CROSS_GSTRIDE = 16 * 256 + 8;            // (the body puts the row count behind the 4096 sums of a slice)
+__global__ __launch_bounds__(256) void cross_reduce_multi_kernel(double* __restrict__ gout, const double* __restrict__ part, int nparts, double rows,
+                                                                 float* __restrict__ fin_r, size_t fin_ldr, float* __restrict__ fin_zneg, int ny_total) {
+	__shared__ double red[16][17];
+	const int j = blockIdx.y;
+	gram_reduce1_body<false>(blockIdx.x, red, gout + (size_t)j * CROSS_GSTRIDE, part + (size_t)j * nparts * (16 * 256), nparts, 16 * 256, rows,
+	                         fin_zneg ? fin_r + (size_t)j * 64 * fin_ldr : nullptr, fin_ldr, fin_zneg ? fin_zneg + (size_t)j * 4096 : nullptr,
+	                         min(64, ny_total - 64 * j));
+}
+
 // gsum: 16 tiles x 256 doubles in f32-MFMA accumulator order (tile 4*ti+tj, row = 4*(lane>>4)+reg, col = lane&15)
+// (ny_total > 0: grid (16, trailing panels) -- slice j reads gsum + j * CROSS_GSTRIDE and writes R's block j and zneg + j * 4096)
 __global__ __launch_bounds__(256) void cross_finish_kernel(float* __restrict__ r, size_t ldr, float* __restrict__ zneg,
-                                                           const double* __restrict__ gsum, int ny) {
+                                                           const double* __restrict__ gsum, int ny, int ny_total = 0) {
+	if (ny_total > 0) {
+		const int j = blockIdx.y;
+		r += (size_t)j * 64 * ldr; zneg += (size_t)j * 4096; gsum += (size_t)j * CROSS_GSTRIDE; ny = min(64, ny_total - 64 * j);
+	}
 	for (int e = blockIdx.x * 256 + threadIdx.x; e < 16 * 256; e += 256 * gridDim.x) {
 		const int t = e >> 8, reg = (e >> 6) & 3, l = e & 63;
 		const int i = 16 * (t >> 2) + 4 * (l >> 4) + reg;
@@ -2000,6 +2022,8 @@ struct ApplyArgs {
 	const float* z;                     // NP x NP, ld NP
 	int nchunks; int cpw; int nwaves;
 	int n_out;                          // UPD only: columns of the output / C input (n is then the contraction length, 64)
+	int multi_cols;                     // UPD only, > 0 (round 4, right-looking coupling): q is the WHOLE trailing matrix, m x multi_cols, z an array of
+	                                    // 64 x 64 operands (-S_j, 4096 floats each); workgroups (., j) update its 64-column panel j
 	double* gpart;                      // GRAMQ only: per-workgroup partial Gram tiles of the OUTPUT block rows (format of gram_bf16_kernel)
 	const unsigned* skip_status;        // optional: the kernel returns at once when *skip_status != 0 (the Cholesky kernel
 	                                    // rejected its Gram matrix: a speculatively enqueued apply then costs a launch, not a pass)
@@ -2495,7 +2519,16 @@ __device__ __forceinline__ void apply_wg_body(const ApplyArgs& a) {
 
 template <int ENGINE, int NT, bool UPD, int ROWS, bool GRAMQ = false>
 __global__ __launch_bounds__(256) void apply_wg_kernel(const ApplyArgs a) {
-	apply_wg_body<ENGINE, NT, UPD, ROWS, false>(a);
+	if constexpr (UPD) {
+		ApplyArgs b = a;                                 // (uniform: the slice's own arguments, in scalar registers)
+		if (a.multi_cols > 0) {
+			const int j = blockIdx.y;
+			b.q = a.q + (size_t)j * 64 * a.ldq; b.z = a.z + (size_t)j * 4096; b.n_out = min(64, a.multi_cols - 64 * j);
+		}
+		apply_wg_body<ENGINE, NT, UPD, ROWS, false>(b);
+	} else {
+		apply_wg_body<ENGINE, NT, UPD, ROWS, false>(a);
+	}
 }
 // the variant that also accumulates Q^T Q: two waves per SIMD (the register allocator is told to stay within 256 registers)
 // fp16 I/O modes: the plain product with halves at both ends (tsqr_mi_qr_f16's native path)

@@ -179,6 +179,15 @@ GramPlan gram_plan(size_t m, size_t n) {
 	return g;
 }
 
+// Coupling partials (cross_kernel: 16 tiles x 256 doubles per workgroup).  A launch covers as many trailing panels as the work space holds
+// workgroup partials for -- every panel with the full workgroup count of one panel pair, so the grouping of the sums (and with it every bit
+// of S) is that of rounds 1-3: up to CROSS_SLOT_CAP slots (32 MiB), never fewer than one panel's.
+constexpr size_t CROSS_SLOT_CAP = 1024;
+size_t cross_slots(size_t m, size_t n) {
+	if (n <= PW) return 0;
+	const size_t nb = (size_t)gram_plan(m, PW).nblocks, ntr = cdiv(n, PW) - 1;
+	return std::max(nb, std::min(ntr * nb, CROSS_SLOT_CAP));
+}
 // extra work space of the one-panel path for 64 < n <= 128 (offsets in floats from WqLayout::wide; the doubles first, 16-byte aligned):
 // [summed tiles 36*256 + row count (+pad)] | [Z 128 x 128 fp32][Z22 fp32 4096]
 constexpr size_t WIDE_G_DOUBLES = 36 * 256 + 8;
@@ -190,7 +199,7 @@ inline size_t wide_part_floats(size_t m) { return (std::min<size_t>((m + 63) / 6
 
 // layout of wq (floats): [stack_b][Z: 4096][S: 4096][R1 copy: n*n][R2: n*n][r3, r4, r5, r6: 4096 each][summed tiles + row count][status]
 constexpr size_t GSUM_DOUBLES = 16 * 256 + 8;          // 16 tiles (coupling) or 10 (Gram) + the row-count word of a row-partitioned run
-struct WqLayout { size_t z, s, r1, r2, r3, r4, r5, r6, gsum, status, wide, total; };
+struct WqLayout { size_t z, s, r1, r2, r3, r4, r5, r6, gsum, status, wide, smulti, gmulti, total; };
 WqLayout wq_layout(size_t m, size_t n) {
 	const Plan p = make_plan(m, n);
 	WqLayout L{};
@@ -209,6 +218,15 @@ WqLayout wq_layout(size_t m, size_t n) {
 	L.status = o; o += 64;
 	L.wide = o;
 	if (n > PW && n <= 2 * PW) o += WIDE_FLOATS;         // the one-panel path for 64 < n <= 128 (sweep_wide)
+	// several 64-column panels (round 4, right-looking coupling): the operands -S_j of the update and the summed coupling tiles of ALL trailing
+	// panels of a finished panel (one slice of 4096 floats / CROSS_GSTRIDE doubles per trailing panel)
+	o = (o + 63) & ~(size_t)63;
+	L.smulti = o; L.gmulti = o;
+	if (n > PW) {
+		const size_t ntr = cdiv(n, PW) - 1;
+		o += ntr * 4096;
+		L.gmulti = o; o += ntr * 2 * (size_t)tsqrmi::CROSS_GSTRIDE;
+	}
 	L.total = o;
 	return L;
 }
@@ -255,6 +273,7 @@ struct Ctx {
 	int dev = 0;
 	float* wq = nullptr; float* wr = nullptr;
 	WqLayout L{};
+	size_t cross_slots = 0;                              // workgroup partials of the coupling launches the work buffer wr holds (cross_slots())
 	HostSig hsig;                                        // pinned words the device can write: status words [0..2] / [4..6], completion flag [3]
 	int policy = 0, gram_level = 2;
 	int min_level = 2;                                   // lowest R-factor engine level used (2 bf16 Gram, 1 fp64 Gram, 0 Householder)
@@ -614,7 +633,11 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 	const size_t nblk = cdiv(a.m, (size_t)ROWS);
 	a.nchunks = (int)nblk;
 	const int wgs = g_set.apply_wgs.load();
-	const size_t want = wgs > 0 ? (size_t)wgs : (size_t)256 * per_cu_cache[c.dev].load();
+	size_t want = wgs > 0 ? (size_t)wgs : (size_t)256 * per_cu_cache[c.dev].load();
+	unsigned gy = 1;
+	if constexpr (UPD) {
+		if (a.multi_cols > 0) { gy = (unsigned)cdiv((size_t)a.multi_cols, PW); want = std::max<size_t>(1, want / gy); }   // (the resident workgroups split over the trailing panels)
+	}
 	a.nwaves = (int)std::min<size_t>(nblk, want);
 	a.cpw = 0;
 	if constexpr (GRAMQ) {
@@ -627,7 +650,7 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 		// 2^20 x 64: the pass ends at 78 us instead of 84)
 		if (a.nwaves == 1024 && per_cu_cache[c.dev].load() == 4) { a.share[0] = 18; a.share[1] = 17; a.share[2] = 15; a.share[3] = 14; a.even_share = 69; }
 	}
-	hipLaunchKernelGGL(kernel, dim3(a.nwaves), dim3(256), lds, c.st, a);
+	hipLaunchKernelGGL(kernel, dim3(a.nwaves, gy), dim3(256), lds, c.st, a);
 	return 0;
 }
 template <int E, int NT, bool UPD> int launch_apply_any(Ctx& c, const tsqrmi::ApplyArgs& a) {
@@ -847,43 +870,57 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 }
 
 // one sweep of 64-wide-panel block QR:  (q, r) <- qr(a);  a is overwritten for n > 64; q may alias a.
+// Panels are coupled by block MODIFIED Gram-Schmidt on the matrix cores (the role of the reference's cuBLAS GEMMs, src/blockqr.cu:92-116),
+// RIGHT-LOOKING since round 4: as soon as panel p is factored, ONE launch each forms S = Qp^T [A_{p+1} ... A_last] (cross_kernel, a grid row
+// per trailing panel), reduces it (writing R's block row and the operands -S_j) and updates every trailing panel (A_j <- A_j - Qp S_j).
+// The same operations on the same operands as the left-looking order of rounds 1-3 (for every trailing panel the updates arrive in the
+// same sequence, every S_j is summed in the same grouping: bit for bit the same factors), but one update launch per PANEL instead of one
+// per panel pair, and the S launches grouped as far as the work space goes: at small row counts the launches finally have the chip's
+// worth of workgroups (4096 x 1024: 3.5 -> 1.8 ms, 32768 x 1024: 3.9 -> 2.2 ms on one box).
 int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n) {
 	const size_t npanels = cdiv(n, PW);
 	for (size_t pi = 0; pi < npanels; pi++) {
 		const size_t P = pi * PW, cc = std::min(PW, n - P);
-		float* ap = a + P * lda;
-		for (size_t bi = 0; bi < pi; bi++) {             // block modified Gram-Schmidt against finished panels
-			const size_t B = bi * PW;
-			ProfScope ps(KC_COUPLE, c.st);
-			// S = Qb^T Ap  (exact fp32 MFMA), written into R(B:B+64, P:P+c); then Ap <- Ap - Qb * S on the mode's MFMA engine
-			const GramPlan g = gram_plan(m, PW);
+		const int rc = panel_qr(c, engine, r_engine, check_now, q + P * ldq, ldq, r + P * ldr + P, ldr, a + P * lda, lda, m, cc);
+		if (rc) return rc;
+		const size_t T0 = P + cc;                        // first trailing column (cc == 64 here: only the last panel may be narrower)
+		if (T0 >= n) break;
+		const size_t ntc = n - T0, ntr = cdiv(ntc, PW);
+		ProfScope ps(KC_COUPLE, c.st);
+		// S_j = Qp^T A_j for every trailing panel j (bf16x3 MFMA products, fp64 sums): launches over groups of trailing panels, as many as
+		// the work space holds workgroup partials for (cross_slots: every panel keeps the workgroup count -- and so the grouping of its
+		// sums -- of a single panel pair; at small row counts that is all of them in one launch)
+		const GramPlan g = gram_plan(m, PW);
+		double* gm = reinterpret_cast<double*>(c.wq + c.L.gmulti);
+		float* sm = c.wq + c.L.smulti;
+		float* rblk = r + T0 * ldr + P;                  // R(P : P + 64, T0 : n)
+		const size_t grp = std::max<size_t>(1, c.cross_slots / (size_t)g.nblocks);
+		for (size_t j0 = 0; j0 < ntr; j0 += grp) {
+			const unsigned gy = (unsigned)std::min(grp, ntr - j0);
+			const int cols = (int)(ntc - PW * j0);       // columns from trailing panel j0 on
 			tsqrmi::CrossArgs ca{};
-			ca.x = q + B * ldq; ca.ldx = ldq; ca.y = ap; ca.ldy = lda; ca.m = m; ca.ny = (int)cc;
+			ca.x = q + P * ldq; ca.ldx = ldq; ca.y = a + (T0 + PW * j0) * lda; ca.ldy = lda; ca.m = m; ca.ny = std::min((int)PW, cols); ca.ny_total = cols;
 			ca.nchunks = g.nch; ca.cpw = g.cpw; ca.nwaves = g.nwaves; ca.part = reinterpret_cast<double*>(c.wr);
-			hipLaunchKernelGGL(tsqrmi::cross_kernel, dim3(g.nblocks), dim3(256), 0, c.st, ca);
-			const int nelem = 16 * 256;
-			if (!c.comm.active()) {
-				// one GPU: the reduction writes -S (operand of the update) and the block of R itself -- one launch less per panel pair
-				hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), ca.part, g.nblocks, nelem, (double)m,
-				                   r + P * ldr + B, ldr, c.wq + c.L.s, (int)cc);
-				HIPCHK(hipGetLastError());
-			} else {
-				hipLaunchKernelGGL(tsqrmi::gram_reduce1_kernel, dim3((nelem + 15) / 16), dim3(256), 0, c.st, c.gsum(), ca.part, g.nblocks, nelem, (double)m,
-				                   nullptr, (size_t)0, nullptr, 0);
-				HIPCHK(hipGetLastError());
-				if (c.comm.allreduce_f64(c.gsum(), (size_t)nelem, c.st)) { t_last_error = "all-reduce of the coupling tiles failed"; return -1; }
-				hipLaunchKernelGGL(tsqrmi::cross_finish_kernel, dim3(16), dim3(256), 0, c.st, r + P * ldr + B, ldr, c.wq + c.L.s, c.gsum(), (int)cc);
-				HIPCHK(hipGetLastError());
-			}
-			tsqrmi::ApplyArgs ua{};
-			ua.a = q + B * ldq; ua.lda = ldq; ua.q = ap; ua.ldq = lda; ua.m = m; ua.n = (int)PW; ua.z = c.wq + c.L.s; ua.n_out = (int)cc;
-			const int rc2 = (engine == 0) ? launch_apply_any<0, 4, true>(c, ua)
-			                              : (engine == 1 ? launch_apply_any<1, 4, true>(c, ua) : launch_apply_any<2, 4, true>(c, ua));
-			if (rc2) return rc2;
+			hipLaunchKernelGGL(tsqrmi::cross_kernel, dim3(g.nblocks, gy), dim3(256), 0, c.st, ca);
+			// one GPU: the reduction writes -S_j (operand of the update) and the block row of R itself; row-partitioned: the sums only
+			const bool fin = !c.comm.active();
+			hipLaunchKernelGGL(tsqrmi::cross_reduce_multi_kernel, dim3(256, gy), dim3(256), 0, c.st, gm + j0 * (size_t)tsqrmi::CROSS_GSTRIDE, ca.part, g.nblocks,
+			                   (double)m, fin ? rblk + j0 * PW * ldr : (float*)nullptr, ldr, fin ? sm + j0 * 4096 : (float*)nullptr, cols);
 			HIPCHK(hipGetLastError());
 		}
-		const int rc = panel_qr(c, engine, r_engine, check_now, q + P * ldq, ldq, r + P * ldr + P, ldr, ap, lda, m, cc);
-		if (rc) return rc;
+		if (c.comm.active()) {
+			// ONE all-reduce for the whole block row (every rank holds the same S afterwards: the same R, the same update)
+			if (c.comm.allreduce_f64(gm, ntr * (size_t)tsqrmi::CROSS_GSTRIDE, c.st)) { t_last_error = "all-reduce of the coupling tiles failed"; return -1; }
+			hipLaunchKernelGGL(tsqrmi::cross_finish_kernel, dim3(16, (unsigned)ntr), dim3(256), 0, c.st, rblk, ldr, sm, gm, 0, (int)ntc);
+			HIPCHK(hipGetLastError());
+		}
+		tsqrmi::ApplyArgs ua{};
+		ua.a = q + P * ldq; ua.lda = ldq; ua.q = a + T0 * lda; ua.ldq = lda; ua.m = m; ua.n = (int)PW; ua.z = sm;
+		ua.n_out = (int)std::min(PW, ntc); ua.multi_cols = (int)ntc;
+		const int rc2 = (engine == 0) ? launch_apply_any<0, 4, true>(c, ua)
+		                              : (engine == 1 ? launch_apply_any<1, 4, true>(c, ua) : launch_apply_any<2, 4, true>(c, ua));
+		if (rc2) return rc2;
+		HIPCHK(hipGetLastError());
 	}
 	return 0;
 }
@@ -1250,6 +1287,7 @@ void init_ctx(Ctx& c, void* wq, void* wr, size_t m_layout, size_t n, void* strea
 	c.wq = reinterpret_cast<float*>(wq);
 	c.wr = reinterpret_cast<float*>(wr);
 	c.L = wq_layout(m_layout, n);
+	c.cross_slots = cross_slots(m_layout, n);
 	c.policy = g_set.policy.load();
 	c.gram_level = g_set.gram_level.load();
 	c.wide = g_set.wide.load() != 0;
@@ -1260,7 +1298,7 @@ size_t working_r_need(size_t m, size_t n) {
 	for (size_t P = 0; P < n; P += PW) {
 		need = std::max(need, make_plan(m, std::min(PW, n - P)).stack_a);
 		need = std::max(need, (n <= PW ? 2 : 1) * gram_plan(m, std::min(PW, n - P)).part_floats);   // (n <= 64: two sets, stream_of_calls_chained)
-		if (n > PW) need = std::max(need, (size_t)gram_plan(m, PW).nblocks * 16 * 256 * 2);
+		if (n > PW) need = std::max(need, cross_slots(m, n) * 16 * 256 * 2);   // (coupling partials: sweep)
 	}
 	if (n > PW && n <= 2 * PW) need = std::max(need, wide_part_floats(m));
 	return need;
