@@ -156,3 +156,41 @@ def test_full_size_c3_both_paths(bq, oracle, torch_cuda):
         rs[policy] = d_r.cpu().numpy().T.astype(np.float64)
     s0 = np.sign(np.diag(rs[0])); s5 = np.sign(np.diag(rs[5]))
     assert np.abs(s0[:, None] * rs[0] - s5[:, None] * rs[5]).max() / np.abs(rs[5]).max() < 1e-6
+
+
+# Several 64-column panels (n > 128): the right-looking coupling of round 4 -- one launch per finished panel forms S for groups of
+# trailing panels and updates all of them (tsqr_mi.hip: sweep; the role of reference src/blockqr.cu:45-178 with its cuBLAS GEMMs) --
+# on shapes with a ragged last panel, padded leading dimensions, in place, and on the reference sweep's own wide family
+# (src/main.cu:93-101: n = 2^10 .. m).  Checked against fp64 LAPACK: residual, orthogonality, sign-normalised R.
+@pytest.mark.parametrize("m,n", [(2000, 330), (4096, 1024), (9211, 200), (1024, 1024), (40000, 257)])
+@pytest.mark.parametrize("mode", ["fp32_notc", "fp32_tc_cor"])
+@pytest.mark.parametrize("reorth", [False, True])
+def test_many_panels_against_lapack(bq, oracle, torch_cuda, m, n, mode, reorth):
+    md = bq.compute_mode[mode]
+    a = oracle.uniform_matrix(m, n, seed=31)
+    st, eng, q, r, _ = run(bq, torch_cuda, a, md, reorth, 0, lda_pad=(7 if m % 2 else 0), ldq_pad=(3 if n % 2 else 0))
+    square = (m == n)
+    assert st == 0 and (eng == 3 or (square and eng in (0, 1, 4)))  # (late panels of a square matrix are ill conditioned: they may step down the ladder)
+    assert np.isfinite(q).all() and np.isfinite(r).all()
+    assert np.abs(np.tril(r, -1)).max() == 0.0
+    square = (m == n)                                               # a random square matrix is ill conditioned (cond ~ n): without a second sweep
+    assert oracle.residual(a, q, r) < RES_TOL                       # Q loses orthogonality like cond * eps, the residual does not
+    assert oracle.orthogonality_fro(q) < (ORTH_TOL if not square else (5e-4 if not reorth else 2e-5))
+    r64 = np.linalg.qr(a.astype(np.float64), mode="r")
+    s = np.sign(np.diag(r64)); s[s == 0] = 1
+    _, rn = oracle.sign_normalise(q, r)
+    tol = PAR_TOL if not square else 5e-3                           # (R of an ill-conditioned matrix is determined to cond * eps only)
+    assert np.abs(rn - s[:, None] * r64).max() / np.abs(r64).max() < tol
+
+
+def test_many_panels_in_place_equals_out_of_place(bq, oracle, torch_cuda):
+    torch = torch_cuda
+    m, n = 6000, 400
+    a = oracle.uniform_matrix(m, n, seed=5)
+    md = bq.compute_mode.fp32_tc_cor
+    st, eng, q, r, _ = run(bq, torch, a, md, False, 0)
+    d_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    d_r = torch.zeros(n, n, device="cuda")
+    bf = bq.buffer(md, False); bf.allocate(m, n)
+    assert bq.qr(d_a, m, d_r, n, d_a, m, m, n, bf) == 0             # q == a
+    assert np.array_equal(d_a.cpu().numpy().T, q) and np.array_equal(d_r.cpu().numpy().T, r)

@@ -1124,19 +1124,36 @@ __device__ __forceinline__ void gram_reduce1_body(const int blk, double (*red)[1
 	const int el = blk * 16 + e;
 	double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 	if (el < nelem) {
-		// the first 512 partials of this thread's stride: 32 loads issued back to back (one memory round trip instead of eight),
-		// then summed in the fixed order s_k += partial(s + 16 (4 i + k)), i ascending
-		double v[32];
+		// the first 512 partials of this thread's stride: U loads issued back to back (one memory round trip instead of eight),
+		// then summed in the fixed order s_k += partial(s + 16 (4 i + k)), i ascending.  U = 32 covers 512 partials; launches with few
+		// partials (small row counts: 16 partials at 4096 rows) take a copy with fewer loads (round 4: the reduction of the coupling
+		// tiles of fifteen trailing panels issued 32 loads per thread where one was needed, 12.6 us per launch) -- the terms a shorter
+		// copy leaves out are exact zeros in the longer one, so the sums are the same bits.
+		auto head = [&](auto uu) {
+			constexpr int U = decltype(uu)::value;
+			double v[U];
 #pragma unroll
-		for (int u = 0; u < 32; u++) {
-			const int b = s + 16 * u;                        // (unconditional loads from a clamped index: no control flow between them)
-			v[u] = part_load(&part[(size_t)min(b, nparts - 1) * nelem + el]);
-		}
+			for (int u = 0; u < U; u++) {
+				const int b = s + 16 * u;                    // (unconditional loads from a clamped index: no control flow between them)
+				v[u] = part_load(&part[(size_t)min(b, nparts - 1) * nelem + el]);
+			}
 #pragma unroll
-		for (int u = 0; u < 32; u++)
-			if (s + 16 * u >= nparts) v[u] = 0.0;
+			for (int u = 0; u < U; u++)
+				if (s + 16 * u >= nparts) v[u] = 0.0;
 #pragma unroll
-		for (int i = 0; i < 8; i++) { s0 += v[4 * i]; s1 += v[4 * i + 1]; s2 += v[4 * i + 2]; s3 += v[4 * i + 3]; }
+			for (int u = 0; u < U; u++) {
+				if ((u & 3) == 0) s0 += v[u];
+				else if ((u & 3) == 1) s1 += v[u];
+				else if ((u & 3) == 2) s2 += v[u];
+				else s3 += v[u];
+			}
+		};
+		if (nparts <= 16) head(std::integral_constant<int, 1>{});
+		else if (nparts <= 32) head(std::integral_constant<int, 2>{});
+		else if (nparts <= 64) head(std::integral_constant<int, 4>{});
+		else if (nparts <= 128) head(std::integral_constant<int, 8>{});
+		else if (nparts <= 256) head(std::integral_constant<int, 16>{});
+		else head(std::integral_constant<int, 32>{});
 		for (int b = s + 512; b < nparts; b += 16) s0 += part_load(&part[(size_t)b * nelem + el]);
 	}
 	red[s][e] = (s0 + s1) + (s2 + s3);
