@@ -160,10 +160,11 @@ def test_four_ranks_unequal_blocks(oracle, policy):
     _check(res, oracle)
 
 
-@pytest.mark.parametrize("n,policy,reorth", [(100, 0, False), (128, 0, True), (100, 1, False)])
+@pytest.mark.parametrize("n,policy,reorth", [(100, 0, False), (128, 0, True), (100, 1, False), (200, 0, False), (330, 0, True)])
 def test_two_ranks_more_than_64_columns(oracle, n, policy, reorth):
     """n > 64 over two ranks: 64-column panels, every coupling coefficient block S = Qb^T Ap all-reduced like the Gram tiles (policy 0)
-    or the panel factors all-gathered (policy 1); both ranks end with the same R and a globally orthogonal Q"""
+    or the panel factors all-gathered (policy 1); both ranks end with the same R and a globally orthogonal Q.  n = 200 / 330: four / six panels,
+    right-looking (round 4): the whole block row of S -- every trailing panel, the last one ragged -- travels in ONE all-reduce per finished panel"""
     import numpy as np
     heights = (9000, 5001)
     res = _run(heights, n, reorth=reorth, policy=policy)
