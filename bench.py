@@ -87,6 +87,42 @@ def synth_block(m_local, n, m_global, row0, seed, device):
     return out
 
 
+def device_probe():
+    """What this box is and what it sustains right now, for reading `value` across boxes (round 4: the same library ran the blocking headline
+    call at 0.163 ms on one box and at 0.196-0.198 ms on five others).  Device properties, plus two library-independent probes taken AFTER all
+    timed windows: a torch bf16 GEMM (8192^3, hipBLASLt) and a torch device-to-device copy of 1 GiB -- plumbing used as a yardstick, not
+    part of the path."""
+    import torch
+    p = torch.cuda.get_device_properties(0)
+    dev = {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
+           "total_memory_gib": round(p.total_memory / 2.0 ** 30, 1)}
+    for k in ("clock_rate", "memory_clock_rate", "L2_cache_size"):
+        if hasattr(p, k):
+            dev[k] = getattr(p, k)
+    try:
+        x = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        y = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        src = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            torch.matmul(x, y); dst.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(10):
+            torch.matmul(x, y)
+        e1.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e2.record()
+        torch.cuda.synchronize()
+        dev["probe_bf16_gemm_8192_tflops"] = round(10 * 2 * 8192.0 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+        dev["probe_copy_1gib_gbs"] = round(10 * 2 * 2.0 ** 30 / (e1.elapsed_time(e2) * 1e-3) / 1e9, 1)
+    except Exception as e:                                           # (a probe must never cost the line)
+        dev["probe_error"] = str(e)[:200]
+    return dev
+
+
 def cpu_baseline(n, mode_name, sample_rows):
     """The reported CPU baseline (north star): host LAPACK sgeqrf + sorgqr (explicit thin Q, F_QR flops -- like for like) on the box's
     host cores, on a bounded sample of the same workload (sample_rows x n, U(-1,1)); sgeqrf alone (F_R) and the CPU oracle
@@ -495,6 +531,8 @@ def main():
         if args.rehearse:
             out["rehearsal"] = True
             out["data"] = "synthetic (CPU rehearsal with the numpy test double: NOT a measurement of the product)"
+        if not args.rehearse:
+            out["device"] = device_probe()
         if world == 1 and not args.no_cpu_baseline and not args.rehearse and not io_half:
             out["cpu_baseline"] = cpu_baseline(n, args.mode, args.cpu_sample_rows)
         print(json.dumps(out))

@@ -876,7 +876,7 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 // The same operations on the same operands as the left-looking order of rounds 1-3 (for every trailing panel the updates arrive in the
 // same sequence, every S_j is summed in the same grouping: bit for bit the same factors), but one update launch per PANEL instead of one
 // per panel pair, and the S launches grouped as far as the work space goes: at small row counts the launches finally have the chip's
-// worth of workgroups (4096 x 1024: 3.5 -> 1.8 ms, 32768 x 1024: 3.9 -> 2.2 ms on one box).
+// worth of workgroups (same-box A/B of the two builds, profiles/r04_experiment_log.md: 4096 x 1024 3.36 -> 1.07 ms, 32768 x 1024 3.87 -> 1.89 ms).
 int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n) {
 	const size_t npanels = cdiv(n, PW);
 	for (size_t pi = 0; pi < npanels; pi++) {
