@@ -217,7 +217,7 @@ WqLayout wq_layout(size_t m, size_t n) {
 	L.gsum = o; o += 2 * GSUM_DOUBLES;
 	L.status = o; o += 64;
 	L.wide = o;
-	if (n > PW && n <= 2 * PW) o += WIDE_FLOATS;         // the one-panel path for 64 < n <= 128 (sweep_wide)
+	if (n > PW) o += WIDE_FLOATS;                        // the one-panel path for 64 < n <= 128 (sweep_wide); n > 128: 128-column blocks of the panel loop (sweep)
 	// several 64-column panels (round 4, right-looking coupling): the operands -S_j of the update and the summed coupling tiles of ALL trailing
 	// panels of a finished panel (one slice of 4096 floats / CROSS_GSTRIDE doubles per trailing panel)
 	o = (o + 63) & ~(size_t)63;
@@ -869,6 +869,8 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 	return apply_rinv(c, engine, qp, ldq, ap, lda, rpp, ldr, m, cc);
 }
 
+int sweep_wide(Ctx& c, int engine, float* q, size_t ldq, float* r, size_t ldr, const float* a, size_t lda, size_t m, size_t n);
+
 // one sweep of 64-wide-panel block QR:  (q, r) <- qr(a);  a is overwritten for n > 64; q may alias a.
 // Panels are coupled by block MODIFIED Gram-Schmidt on the matrix cores (the role of the reference's cuBLAS GEMMs, src/blockqr.cu:92-116),
 // RIGHT-LOOKING since round 4: as soon as panel p is factored, ONE launch each forms S = Qp^T [A_{p+1} ... A_last] (cross_kernel, a grid row
@@ -879,12 +881,35 @@ int panel_qr(Ctx& c, int engine, int r_engine, bool check_now, float* qp, size_t
 // worth of workgroups (same-box A/B of the two builds, profiles/r04_experiment_log.md: 4096 x 1024 3.36 -> 1.07 ms, 32768 x 1024 3.87 -> 1.89 ms).
 int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq, float* r, size_t ldr, float* a, size_t lda, size_t m, size_t n) {
 	const size_t npanels = cdiv(n, PW);
-	for (size_t pi = 0; pi < npanels; pi++) {
+	// 128-COLUMN BLOCKS (round 4): while the bf16-split level accepts them, two neighbouring panels are factored at once by the one-panel
+	// path of 64 < n <= 128 (sweep_wide: ONE Gram pass over 128 columns, the two-block Cholesky factor, ONE apply pass -- speculative, A
+	// untouched when the verdict over both blocks rejects) instead of panel + coupling + panel: a third of the passes over those columns
+	// and one factorisation launch instead of two + a coupling.  Their two 64-column halves then couple with everything behind the block,
+	// one after the other, as any two finished panels.  A rejected block (and everything after it in this sweep) takes the 64-column way.
+	bool try_wide = c.wide && c.policy == 0 && r_engine == 2 && check_now && !c.comm.active() && n > 2 * PW;
+	for (size_t pi = 0; pi < npanels;) {
 		const size_t P = pi * PW, cc = std::min(PW, n - P);
-		const int rc = panel_qr(c, engine, r_engine, check_now, q + P * ldq, ldq, r + P * ldr + P, ldr, a + P * lda, lda, m, cc);
-		if (rc) return rc;
-		const size_t T0 = P + cc;                        // first trailing column (cc == 64 here: only the last panel may be narrower)
+		size_t blockw = cc;                              // columns factored in this step
+		bool wide_blk = false;
+		if (try_wide && n - P > PW) {
+			const size_t w = std::min(2 * PW, n - P);
+			int rcw = sweep_wide(c, engine, q + P * ldq, ldq, r + P * ldr + P, ldr, a + P * lda, lda, m, w);
+			if (rcw) return rcw;
+			unsigned stw = 1u;
+			rcw = read_status(c, c.slot, &stw);
+			if (rcw) return rcw;
+			if (stw == 0) { wide_blk = true; blockw = w; c.min_level = std::min(c.min_level, 2); }
+			else try_wide = false;
+		}
+		if (!wide_blk) {
+			const int rc = panel_qr(c, engine, r_engine, check_now, q + P * ldq, ldq, r + P * ldr + P, ldr, a + P * lda, lda, m, cc);
+			if (rc) return rc;
+		}
+		pi += cdiv(blockw, PW);
+		const size_t T0 = P + blockw;                    // first trailing column (blockw is a multiple of 64 here: only the last block may be ragged)
 		if (T0 >= n) break;
+		for (size_t X0 = P; X0 < T0; X0 += PW) {         // the finished 64-column panels of this step, one after the other
+		const size_t Pc = X0;
 		const size_t ntc = n - T0, ntr = cdiv(ntc, PW);
 		ProfScope ps(KC_COUPLE, c.st);
 		// S_j = Qp^T A_j for every trailing panel j (bf16x3 MFMA products, fp64 sums): launches over groups of trailing panels, as many as
@@ -893,13 +918,13 @@ int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq
 		const GramPlan g = gram_plan(m, PW);
 		double* gm = reinterpret_cast<double*>(c.wq + c.L.gmulti);
 		float* sm = c.wq + c.L.smulti;
-		float* rblk = r + T0 * ldr + P;                  // R(P : P + 64, T0 : n)
+		float* rblk = r + T0 * ldr + Pc;                 // R(Pc : Pc + 64, T0 : n)
 		const size_t grp = std::max<size_t>(1, c.cross_slots / (size_t)g.nblocks);
 		for (size_t j0 = 0; j0 < ntr; j0 += grp) {
 			const unsigned gy = (unsigned)std::min(grp, ntr - j0);
 			const int cols = (int)(ntc - PW * j0);       // columns from trailing panel j0 on
 			tsqrmi::CrossArgs ca{};
-			ca.x = q + P * ldq; ca.ldx = ldq; ca.y = a + (T0 + PW * j0) * lda; ca.ldy = lda; ca.m = m; ca.ny = std::min((int)PW, cols); ca.ny_total = cols;
+			ca.x = q + Pc * ldq; ca.ldx = ldq; ca.y = a + (T0 + PW * j0) * lda; ca.ldy = lda; ca.m = m; ca.ny = std::min((int)PW, cols); ca.ny_total = cols;
 			ca.nchunks = g.nch; ca.cpw = g.cpw; ca.nwaves = g.nwaves; ca.part = reinterpret_cast<double*>(c.wr);
 			hipLaunchKernelGGL(tsqrmi::cross_kernel, dim3(g.nblocks, gy), dim3(256), 0, c.st, ca);
 			// one GPU: the reduction writes -S_j (operand of the update) and the block row of R itself; row-partitioned: the sums only
@@ -915,12 +940,13 @@ int sweep(Ctx& c, int engine, int r_engine, bool check_now, float* q, size_t ldq
 			HIPCHK(hipGetLastError());
 		}
 		tsqrmi::ApplyArgs ua{};
-		ua.a = q + P * ldq; ua.lda = ldq; ua.q = a + T0 * lda; ua.ldq = lda; ua.m = m; ua.n = (int)PW; ua.z = sm;
+		ua.a = q + Pc * ldq; ua.lda = ldq; ua.q = a + T0 * lda; ua.ldq = lda; ua.m = m; ua.n = (int)PW; ua.z = sm;
 		ua.n_out = (int)std::min(PW, ntc); ua.multi_cols = (int)ntc;
 		const int rc2 = (engine == 0) ? launch_apply_any<0, 4, true>(c, ua)
 		                              : (engine == 1 ? launch_apply_any<1, 4, true>(c, ua) : launch_apply_any<2, 4, true>(c, ua));
 		if (rc2) return rc2;
 		HIPCHK(hipGetLastError());
+		}
 	}
 	return 0;
 }
@@ -1300,7 +1326,7 @@ size_t working_r_need(size_t m, size_t n) {
 		need = std::max(need, (n <= PW ? 2 : 1) * gram_plan(m, std::min(PW, n - P)).part_floats);   // (n <= 64: two sets, stream_of_calls_chained)
 		if (n > PW) need = std::max(need, cross_slots(m, n) * 16 * 256 * 2);   // (coupling partials: sweep)
 	}
-	if (n > PW && n <= 2 * PW) need = std::max(need, wide_part_floats(m));
+	if (n > PW) need = std::max(need, wide_part_floats(m));   // (sweep_wide: the whole matrix for n <= 128, 128-column blocks of the panel loop beyond)
 	return need;
 }
 
