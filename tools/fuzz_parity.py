@@ -23,8 +23,10 @@ def _case(rng, g, it, verbose):
             n = rng.randint(1, 64); m = rng.randint(n, 400)
         elif kind < 0.8:
             n = rng.randint(1, 64); m = rng.randint(n, 70000)
-        else:
+        elif kind < 0.93:
             n = rng.randint(65, 200); m = rng.randint(n, 40000)
+        else:                                                          # several 128-column blocks, ragged last block / panel (round 4)
+            n = rng.randint(201, 460); m = rng.randint(n, 20000)
         lda, ldq, ldr = m + rng.choice([0, 0, 1, 3, 8, 37]), m + rng.choice([0, 0, 2, 5, 64]), n + rng.choice([0, 0, 1, 7])
         mode = rng.choice([bq.compute_mode.fp32_notc, bq.compute_mode.fp32_tc_cor, bq.compute_mode.fp32_tc_nocor])
         reorth = rng.random() < 0.3
