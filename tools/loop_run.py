@@ -14,6 +14,8 @@ mode = bq.compute_mode[sys.argv[4]] if len(sys.argv) > 4 else bq.compute_mode.fp
 reorth = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
 bq.set_policy(int(sys.argv[6]) if len(sys.argv) > 6 else 0)
 bq.set_loop_depth(int(sys.argv[7]) if len(sys.argv) > 7 else 3)
+if os.environ.get("TSQR_TUNE_APPLY_WAVES") or os.environ.get("TSQR_TUNE_GRAM_WAVES"):   # grid experiments (tsqr_mi_set_tuning2)
+    bq.lib().tsqr_mi_set_tuning2(int(os.environ.get("TSQR_TUNE_GRAM_WAVES", "0")), int(os.environ.get("TSQR_TUNE_APPLY_WAVES", "0")))
 kind = sys.argv[8] if len(sys.argv) > 8 else ""
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 if kind == "c5":

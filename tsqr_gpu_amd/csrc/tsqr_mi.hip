@@ -646,9 +646,51 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 		c.gramq_nparts = a.nwaves;
 	}
 	if constexpr (!UPD && !GRAMQ && ROWS == 64) {
-		// four workgroups per CU on the whole chip: uneven shares by XCD parity and by dispatch round (apply_wg_body; measured on
-		// 2^20 x 64: the pass ends at 78 us instead of 84)
-		if (a.nwaves == 1024 && per_cu_cache[c.dev].load() == 4) { a.share[0] = 18; a.share[1] = 17; a.share[2] = 15; a.share[3] = 14; a.even_share = 69; }
+		// Four workgroups per CU on the whole chip: uneven shares by XCD parity and by dispatch round (apply_wg_body; round 3, on every box
+		// looked at THEN: the pass ends at 78 us instead of 84).  Round 4: on five boxes in a row the same shares COST 5-6 % of the call
+		// (blocking 194.9-198.9 us against 186.1-188.1 with equal shares, chained 170.3-173.2 against 159.4-161.1; three interleaved runs,
+		// profiles/r04_experiment_log.md) -- the XCD asymmetry they answer is a property of the box's state, not of the chip.  So the
+		// choice is MEASURED once per process and device (and per side of the cache size), on the first large out-of-place pass: the two
+		// candidates (shares by XCD parity and round / equal) run the pass itself in turn under HIP events, four times each (Q = A Z is the
+		// same whoever computes a block: the last run leaves the result), ~0.7 ms once; the uneven shares are taken only when they are 2 %
+		// faster.  TSQR_MI_APPLY_SHARES=0 / 1 / 2 pins equal / both / by round only.
+		if (a.nwaves == 1024 && per_cu_cache[c.dev].load() == 4) {
+			static const int pinned = env_int("TSQR_MI_APPLY_SHARES", -1);
+			static std::atomic<int> chosen[MAX_DEV][2];      // 0 not measured yet, 1 both, 2 rounds only, 3 equal; [1]: a matrix beyond the Infinity Cache
+			auto set_mode = [](tsqrmi::ApplyArgs& x, int mode) {
+				x.share[0] = x.share[1] = x.share[2] = x.share[3] = 0; x.even_share = 0;
+				if (mode == 1 || mode == 2) { x.share[0] = 18; x.share[1] = 17; x.share[2] = 15; x.share[3] = 14; x.even_share = (mode == 1) ? 69 : 64; }
+			};
+			const double bytes = (double)a.m * (double)a.n * sizeof(float);
+			const int cls = bytes > 256.0 * 1048576.0 ? 1 : 0;
+			int mode = pinned == 0 ? 3 : (pinned == 1 ? 1 : (pinned == 2 ? 2 : chosen[c.dev][cls].load()));
+			const bool big = bytes >= 128.0 * 1048576.0;
+			if (mode == 0 && big && reinterpret_cast<const void*>(a.q) != reinterpret_cast<const void*>(a.a) && !t_prof.on) {
+				constexpr int REPS = 4;                          // interleaved: uneven, equal, uneven, equal, ...
+				hipEvent_t ev[2 * REPS + 1];
+				bool ok = true;
+				for (auto& e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+				if (ok) {
+					for (int i = 0; i < 2 * REPS; i++) {
+						tsqrmi::ApplyArgs x = a;
+						set_mode(x, (i & 1) ? 3 : 1);
+						(void)hipEventRecord(ev[i], c.st);
+						hipLaunchKernelGGL(kernel, dim3(a.nwaves, gy), dim3(256), lds, c.st, x);
+					}
+					(void)hipEventRecord(ev[2 * REPS], c.st);
+					ok = hipEventSynchronize(ev[2 * REPS]) == hipSuccess;
+					float t[2] = {0.f, 0.f};
+					for (int i = 0; i < 2 * REPS && ok; i++) { float ms = 0.f; ok = hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess; t[i & 1] += ms; }
+					// (a speculative pass that skipped itself -- rejected Gram matrix -- measures nothing: ask again next time)
+					if (ok && t[0] > 0.01f * REPS && t[1] > 0.01f * REPS)
+						chosen[c.dev][cls].store(t[0] < 0.98f * t[1] ? 1 : 3);   // equal shares unless the uneven ones are clearly (2 %) faster
+				}
+				for (auto& e : ev) (void)hipEventDestroy(e);
+				(void)hipGetLastError();
+				return 0;                                    // (the pass has run)
+			}
+			set_mode(a, mode == 0 ? 3 : mode);
+		}
 	}
 	hipLaunchKernelGGL(kernel, dim3(a.nwaves, gy), dim3(256), lds, c.st, a);
 	return 0;
