@@ -1390,7 +1390,7 @@ int qr_dist_common(Ctx& c, int mode, int reorth, float* q, size_t ldq, float* r,
 
 extern "C" {
 
-int tsqr_mi_version(void) { return 400; }
+int tsqr_mi_version(void) { return 410; }
 const char* tsqr_mi_last_error(void) { return t_last_error.c_str(); }
 
 size_t tsqr_mi_batch_size_log2(size_t m) { return ref_bs_log2(m); }
