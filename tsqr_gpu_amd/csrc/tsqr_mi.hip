@@ -652,7 +652,7 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 		// profiles/r04_experiment_log.md) -- the XCD asymmetry they answer is a property of the box's state, not of the chip.  So the
 		// choice is MEASURED once per process and device (and per side of the cache size), on the first large out-of-place pass: the two
 		// candidates (shares by XCD parity and round / equal) run the pass itself in turn under HIP events, four times each (Q = A Z is the
-		// same whoever computes a block: the last run leaves the result), ~0.7 ms once; the uneven shares are taken only when they are 2 %
+		// same whoever computes a block: the last run leaves the result), ~0.7 ms once; the uneven shares are taken only when they are 1 %
 		// faster.  TSQR_MI_APPLY_SHARES=0 / 1 / 2 pins equal / both / by round only.
 		if (a.nwaves == 1024 && per_cu_cache[c.dev].load() == 4) {
 			static const int pinned = env_int("TSQR_MI_APPLY_SHARES", -1);
@@ -683,7 +683,7 @@ template <int E, int NT, bool UPD, int ROWS, bool GRAMQ = false> int launch_appl
 					for (int i = 0; i < 2 * REPS && ok; i++) { float ms = 0.f; ok = hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess; t[i & 1] += ms; }
 					// (a speculative pass that skipped itself -- rejected Gram matrix -- measures nothing: ask again next time)
 					if (ok && t[0] > 0.01f * REPS && t[1] > 0.01f * REPS)
-						chosen[c.dev][cls].store(t[0] < 0.98f * t[1] ? 1 : 3);   // equal shares unless the uneven ones are clearly (2 %) faster
+						chosen[c.dev][cls].store(t[0] < 0.99f * t[1] ? 1 : 3);   // equal shares unless the uneven ones are (1 %) faster: 3 % on the boxes they were tuned on, 5-10 % SLOWER elsewhere
 				}
 				for (auto& e : ev) (void)hipEventDestroy(e);
 				(void)hipGetLastError();
