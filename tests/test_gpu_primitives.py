@@ -70,3 +70,27 @@ def test_bf16_three_way_split(st):
     assert rel.max() < 2.0 ** -23                                       # three 8-bit pieces carry the fp32 mantissa
     ref_h = ((x.view(np.uint32).astype(np.uint64) + 0x7FFF + ((x.view(np.uint32) >> 16) & 1)) >> 16 << 16).astype(np.uint32).view(np.float32)
     assert np.array_equal(h, ref_h)                                     # hi = round-to-nearest-even bf16
+
+
+def test_apply_result_does_not_depend_on_the_block_shares(st):
+    """The library picks the apply pass's block shares by measurement on the box it runs on (round 4) -- legitimate only because Q = A Z is
+    bit for bit the same whoever computes a block.  apply_wg_kernel's body under the share settings the library can take (equal, by
+    dispatch round only, by XCD parity and round) and two others: identical Q."""
+    import ctypes
+    L, torch = st
+    L.tsqr_selftest_apply_balance.restype = ctypes.c_int
+    L.tsqr_selftest_apply_balance.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 5
+    m, nwg = 1 << 20, 1024
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    a = torch.rand(64, m, generator=g, device="cuda") * 2 - 1
+    z = torch.triu(torch.rand(64, 64, generator=g, device="cuda")).T.contiguous()
+    q = torch.empty(64, m, device="cuda")
+    qref = None
+    for sh in ((0, 0, 0, 0, 0), (18, 17, 15, 14, 64), (18, 17, 15, 14, 69), (20, 17, 14, 13, 72), (16, 16, 16, 16, 60)):
+        stamps = torch.zeros(4 * nwg, dtype=torch.int64, device="cuda")
+        q.fill_(float("nan"))
+        assert L.tsqr_selftest_apply_balance(_p(q), _p(a), m, m, _p(z), nwg, _p(stamps), 1, *sh) == 0
+        assert not torch.isnan(q).any()
+        if qref is None:
+            qref = q.clone()
+        assert torch.equal(q, qref), "Q depends on the block shares %s" % (sh,)
